@@ -1,0 +1,50 @@
+"""Builds libbisbm_hip.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.
+
+-ffp-contract=off is part of the contract, not a tuning flag: the FP64 expressions of the dS /
+Hastings path must round exactly like the host code they are compared with (no FMA contraction)."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libbisbm_hip.so")
+SOURCES = ["bisbm_kernels.hip", "bisbm_runtime.hip", "bisbm_io.cpp"]
+HEADERS = ["bisbm_device.hpp", "bisbm_kernels.hpp", os.path.join("..", "..", "include", "bisbm.h"),
+           os.path.join("..", "..", "include", "bisbm_io.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
+         "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the engine is HIP-only and cannot be built without ROCm")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    if verbose and r.stderr:
+        print(r.stderr, file=sys.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

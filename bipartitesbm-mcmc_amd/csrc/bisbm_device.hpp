@@ -1,0 +1,315 @@
+// bisbm_device.hpp -- device-side building blocks of the MH sweep engine (gfx950, wave64).
+//
+// One wavefront owns one Markov chain.  Everything here is wave-synchronous: control flow is
+// wave-uniform, lanes parallelise the per-node work (lane j <-> neighbour j for the CSR walk,
+// lane t <-> opposite-type block t for the dS / Hastings terms and the proposal CDF).
+//
+// Reference lines cited as <file>:<line> relative to /root/reference/src.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bisbm {
+
+constexpr int kWave = 64;
+constexpr int kQNmax = 10000;  // blockmodel.cc:48 init_q_cache(10000)
+
+enum : int { RNG_PHILOX = 0, RNG_COMPAT = 1 };
+enum : int { SCHED_EXPONENTIAL = 0, SCHED_LINEAR = 1, SCHED_LOGARITHMIC = 2, SCHED_CONSTANT = 3, SCHED_ABRUPT = 4 };
+enum : uint32_t { PHX_STEP_A = 0, PHX_STEP_B = 1, PHX_SWEEP_KEY = 2, PHX_INIT_SHUFFLE = 3 };
+
+// ------------------------------------------------------------------------------------------
+// cross-lane helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ double bcast(double x, int src) { return __shfl(x, src, kWave); }
+__device__ __forceinline__ int bcast(int x, int src) { return __shfl(x, src, kWave); }
+
+// Fixed 64-leaf xor butterfly, levels 1,2,4,8,16,32: the summation tree of Philox mode.  FP add is
+// commutative, so every lane ends with the same bits.
+__device__ __forceinline__ double butterfly_sum(double x) {
+#pragma unroll
+    for (int lvl = 1; lvl < kWave; lvl <<= 1) x = x + __shfl_xor(x, lvl, kWave);
+    return x;
+}
+
+// inclusive prefix sum over the wave (int64 to be safe against 2^31 edge totals)
+__device__ __forceinline__ long long wave_inclusive_scan(long long x) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        long long y = __shfl_up(x, d, kWave);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+
+// ------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11) and the production draw definitions
+// ------------------------------------------------------------------------------------------
+struct U4 {
+    uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0;
+        c1 = lo1;
+        c2 = n2;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ U4 phx_draw(uint64_t seed, uint32_t chain, uint32_t purpose, uint64_t idx) {
+    return philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), chain, purpose, (uint32_t)seed,
+                         (uint32_t)(seed >> 32));
+}
+
+// 53-bit uniform in [0,1) from two words
+__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
+    const uint64_t b = ((uint64_t)hi << 32) | lo;
+    return (double)(b >> 11) * 0x1.0p-53;
+}
+
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+
+// Keyed bijection of [0,n): 4-round alternating Feistel network on max(2, bitlen(n-1)) bits with
+// cycle walking.  Gives the per-sweep visit order (and the label shuffle) without storing a
+// permutation: position i is evaluated on the fly, any lane can evaluate any position.
+struct Feistel {
+    uint32_t k0, k1, k2, k3;
+    uint32_t n, wa, wb;
+    __device__ __forceinline__ void init(U4 keys, uint32_t n_) {
+        k0 = keys.x;
+        k1 = keys.y;
+        k2 = keys.z;
+        k3 = keys.w;
+        n = n_;
+        uint32_t b = 0;
+        while (((uint64_t)1 << b) < (uint64_t)n_) ++b;
+        if (b < 2) b = 2;
+        wa = b / 2;
+        wb = b - wa;
+    }
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const {
+        if (n <= 1) return 0;
+        const uint32_t ma = (1u << wa) - 1u, mb = (1u << wb) - 1u;
+        uint32_t x = i;
+        do {
+            uint32_t A = x >> wb, B = x & mb;
+            // widths alternate (wa,wb) -> (wb,wa) -> (wa,wb) -> ...
+            uint32_t nA, nB;
+            nA = B; nB = A ^ (mix32(B ^ k0) & ma); A = nA; B = nB;  // A: wb bits, B: wa bits
+            nA = B; nB = A ^ (mix32(B ^ k1) & mb); A = nA; B = nB;  // A: wa bits, B: wb bits
+            nA = B; nB = A ^ (mix32(B ^ k2) & ma); A = nA; B = nB;
+            nA = B; nB = A ^ (mix32(B ^ k3) & mb); A = nA; B = nB;
+            x = (A << wb) | B;
+        } while (x >= n);
+        return x;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// std::mt19937 + libstdc++-11 distributions, state in LDS (compat mode)
+// ------------------------------------------------------------------------------------------
+struct Mt {
+    uint32_t* mt;  // 624 words in LDS
+    int idx;       // wave-uniform
+
+    // regenerate all 624 words; chunks of 64 lanes, reads of a chunk complete before its writes
+    __device__ void twist() {
+        const int lane = lane_id();
+        for (int c = 0; c < 624; c += kWave) {
+            const int k = c + lane;
+            uint32_t v = 0;
+            if (k < 624) {
+                const uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+                v = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            __syncthreads();
+            if (k < 624) mt[k] = v;
+            __syncthreads();
+        }
+        idx = 0;
+    }
+    __device__ uint32_t next() {
+        if (idx >= 624) twist();
+        uint32_t y = mt[idx++];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= (y >> 18);
+        return y;
+    }
+    // uniform_real_distribution<double>(0,1) -> generate_canonical<double,53> (random.tcc:3348-3384)
+    __device__ double canonical() {
+        const double x0 = (double)next();
+        const double x1 = (double)next();
+        double r = (x0 + x1 * 4294967296.0) / 18446744073709551616.0;
+        if (r >= 1.0) r = 0x1.fffffffffffffp-1;  // nextafter(1, 0)
+        return r;
+    }
+    // Lemire downscale for a 32-bit URBG (uniform_int_dist.h:245-272)
+    __device__ uint32_t lemire(uint32_t range) {
+        uint64_t product = (uint64_t)next() * (uint64_t)range;
+        uint32_t low = (uint32_t)product;
+        if (low < range) {
+            const uint32_t threshold = (0u - range) % range;
+            while (low < threshold) {
+                product = (uint64_t)next() * (uint64_t)range;
+                low = (uint32_t)product;
+            }
+        }
+        return (uint32_t)(product >> 32);
+    }
+};
+
+// std::shuffle (stl_algo.h:3729-3793) of v[0..n) with wave-uniform control flow.  T is uint32_t
+// (vlist) or uint8_t (labels).  Every lane computes the same indices; lane 0 stores.
+template <class T>
+__device__ void mt_shuffle(Mt& g, T* v, uint32_t n) {
+    if (n == 0) return;
+    const int lane = lane_id();
+    auto swap_at = [&](uint32_t i, uint32_t j) {
+        const T a = v[i], b = v[j];
+        __syncthreads();
+        if (lane == 0) {
+            v[i] = b;
+            v[j] = a;
+        }
+        __syncthreads();
+    };
+    if (0xFFFFFFFFull / n >= n) {
+        uint32_t i = 1;
+        if ((n % 2) == 0) {
+            swap_at(i, g.lemire(2));
+            ++i;
+        }
+        while (i < n) {
+            const uint32_t s = i + 1;
+            const uint32_t x = g.lemire(s * (s + 1));
+            swap_at(i, x / (s + 1));
+            ++i;
+            swap_at(i, x % (s + 1));
+            ++i;
+        }
+        return;
+    }
+    for (uint32_t i = 1; i < n; ++i) swap_at(i, g.lemire(i + 1));
+}
+
+// ------------------------------------------------------------------------------------------
+// numerics: lgamma table, log_q table / approximation (support/cache.hh, int_part.{hh,cc}, spence.cc)
+// ------------------------------------------------------------------------------------------
+struct Tables {
+    const double* lg;  // lg[i] = glibc lgamma(i), lg[0] = +inf (cache.cc:64-79), built on the host
+    uint64_t lg_size;
+    const double* q;    // q[n * q_stride + k], n <= 10000, k <= q_kcap (int_part.cc:34-51)
+    uint32_t q_stride;  // q_kcap + 1
+};
+
+__device__ __forceinline__ double lgamma_fast(const Tables& t, long long x) {
+    if ((unsigned long long)x < t.lg_size) return t.lg[x];
+    return NAN;  // the host sizes the table to cover every index the kernels can form (bisbm_create)
+}
+
+__device__ __forceinline__ double lbinom_fast(const Tables& t, unsigned long long N, unsigned long long k) {
+    if (N == 0 || k == 0 || k > N) return 0;  // util.hh:41-47
+    return (lgamma_fast(t, (long long)(N + 1)) - lgamma_fast(t, (long long)(k + 1))) -
+           lgamma_fast(t, (long long)(N - k + 1));
+}
+
+__device__ __forceinline__ double polevl8(double x, const double* c) {  // spence.cc:91-106, N = 7
+    double ans = c[0];
+#pragma unroll
+    for (int i = 1; i <= 7; ++i) ans = ans * x + c[i];
+    return ans;
+}
+
+__device__ inline double spence(double x) {  // spence.cc:108-154 (Cephes dilogarithm)
+    const double A[8] = {4.65128586073990045278E-5, 7.31589045238094711071E-3, 1.33847639578309018650E-1,
+                         8.79691311754530315341E-1, 2.71149851196553469920E0,  4.25697156008121755724E0,
+                         3.29771340985225106936E0,  1.00000000000000000126E0};
+    const double B[8] = {6.90990488912553276999E-4, 2.54043763932544379113E-2, 2.82974860602568089943E-1,
+                         1.41172597751831069617E0,  3.63800533345137075418E0,  5.03278880143316990390E0,
+                         3.54771340985225096217E0,  9.99999999999999998740E-1};
+    const double kPi = 3.14159265358979323846;
+    double w, y, z;
+    int flag = 0;
+    if (x < 0.0) return NAN;
+    if (x == 1.0) return 0.0;
+    if (x == 0.0) return kPi * kPi / 6.0;
+    if (x > 2.0) {
+        x = 1.0 / x;
+        flag |= 2;
+    }
+    if (x > 1.5) {
+        w = (1.0 / x) - 1.0;
+        flag |= 2;
+    } else if (x < 0.5) {
+        w = -x;
+        flag |= 1;
+    } else
+        w = x - 1.0;
+    y = -w * polevl8(w, A) / polevl8(w, B);
+    if (flag & 1) y = (kPi * kPi) / 6.0 - log(x) * log1p(-x) - y;
+    if (flag & 2) {
+        z = log(x);
+        y = -0.5 * z * z - y;
+    }
+    return y;
+}
+
+__device__ inline double get_v(double u) {  // int_part.cc:77-87
+    double v = u;
+    double delta = 1;
+    int guard = 0;
+    while (delta > 1e-8 && guard < 1000) {  // the guard only bounds a wave that would never finish
+        const double n_v = u * sqrt(spence(exp(-v)));
+        delta = fabs(n_v - v);
+        v = n_v;
+        ++guard;
+    }
+    return v;
+}
+
+__device__ __noinline__ double log_q_approx(const Tables& t, unsigned long long n, unsigned long long k) {
+    const double kPi = 3.14159265358979323846;
+    if ((double)k < pow((double)n, 1 / 4.))  // int_part.cc:73-75,90-91
+        return lbinom_fast(t, n - 1, k - 1) - lgamma_fast(t, (long long)(k + 1));
+    const double u = (double)k / sqrt((double)n);  // int_part.cc:92-97
+    const double v = get_v(u);
+    const double lf = log(v) - log1p(-exp(-v) * (1 + u * u / 2)) / 2 - log(2.) * 3 / 2. - log(u) - log(kPi);
+    const double g = 2 * v / u - u * log1p(-exp(-v));
+    return lf - log((double)n) + sqrt((double)n) * g;
+}
+
+__device__ inline double log_q(const Tables& t, int n, int k) {  // int_part.hh:27-37
+    if (n <= 0 || k < 1) return 0;
+    if (k > n) k = n;
+    if (n < kQNmax + 1) {
+        if ((uint32_t)k >= t.q_stride) return NAN;  // outside the uploaded columns (cannot happen on the sweep path)
+        return t.q[(size_t)n * t.q_stride + (size_t)k];
+    }
+    return log_q_approx(t, (unsigned long long)n, (unsigned long long)k);
+}
+
+}  // namespace bisbm

@@ -1,0 +1,702 @@
+// bisbm_kernels.hip -- HIP kernels of the MH sweep engine (gfx950 / CDNA4, wave64).
+//
+//   sweep_kernel<RNG>        metropolis_hasting::anneal -> step -> transition_ratio
+//                            (metropolis_hasting.cc:42-192) + single_vertex_change
+//                            (blockmodel.cc:613-637) + apply_mcmc_moves (blockmodel.cc:461-503):
+//                            one wavefront = one chain, persistent over all sweeps of the call.
+//   state_build_kernel       init_bisbm (blockmodel.cc:682-746): n_r, m, m_r, eta from labels.
+//   shuffle_*_kernel         shuffle_bisbm (blockmodel.cc:672-680).
+//   entropy_kernel           the block-state part of entropy() (blockmodel.cc:758-771).
+//   marginals_kernel         per-node label histogram over chains.
+//   log_q_probe_kernel       numerics probe for tests.
+//
+// Data layout in HBM (per handle; chain-major so a chain's arrays are contiguous):
+//   rowptr u32[n+1], col u32[2E] (edge-file order)          shared by all chains
+//   labels u8 [chain][label_stride]                          node -> block (K <= 256)
+//   m      i32[chain][ka*kb]   a x b quadrant of the symmetric block matrix
+//   m_r,n_r i32[chain][K];  eta u32[chain][K*(maxdeg+1)]
+//   lgamma f64[lg_size], log_q f64[10001*(kcap+1)]           host-built tables (glibc values)
+// During a sweep kernel the chain's m (row stride padded to an odd number of banks so that both
+// row and column walks are conflict-free), m_r, n_r, the k_v histogram and (when it fits) eta
+// live in LDS; labels stay in HBM and are gathered through the CSR walk.
+//
+// Compiled with -ffp-contract=off: FP64 expressions must round exactly like the host code they
+// are compared with (no FMA contraction).
+#include "bisbm_kernels.hpp"
+
+namespace bisbm {
+
+// ------------------------------------------------------------------------------------------
+// per-chain context held in registers / LDS while a sweep kernel runs
+// ------------------------------------------------------------------------------------------
+struct ChainCtx {
+    // LDS
+    int32_t* mq;     // ka * S
+    int32_t* mr;     // K
+    int32_t* nr;     // K
+    int32_t* hist;   // max(ka, kb)
+    uint32_t* eta;   // K * (maxdeg+1), LDS or global
+    // global
+    uint8_t* labels;
+    // shape
+    uint32_t ka, kb, K, S, D;  // S = LDS row stride of mq, D = maxdeg + 1
+    uint32_t na;
+    double epsilon;
+    // MH object state
+    double cum_dS;
+    double accu_r;
+};
+
+// m[own block i][opposite block j] for a node of the given type, from the a x b quadrant
+__device__ __forceinline__ int32_t& Mx(const ChainCtx& c, bool type_b, uint32_t i_own, uint32_t j_oth) {
+    return type_b ? c.mq[j_oth * c.S + i_own] : c.mq[i_own * c.S + j_oth];
+}
+
+__device__ __forceinline__ double temperature(const SweepParams& p, uint64_t t) {
+    switch (p.schedule) {  // metropolis_hasting.cc:10-37, arithmetic types as the C++ promotes them
+        case SCHED_CONSTANT:
+            return (double)p.kw0;
+        case SCHED_ABRUPT:
+            return ((float)t < p.kw0) ? 1. : 0.;
+        case SCHED_LINEAR:
+            return (double)(p.kw0 - p.kw1 * (float)t);
+        case SCHED_EXPONENTIAL:
+            if (t < p.T_len) return p.T_tab[t];  // host table: glibc pow, incl. the subnormal tail
+            if (p.T_zero_after) return 0.;
+            return (double)p.kw0 * pow((double)p.kw1, (double)t);
+        default: {  // SCHED_LOGARITHMIC
+            if (t < p.T_len) return p.T_tab[t];
+            const float x = (float)t + p.kw1;
+            const unsigned long long i = (unsigned long long)x;
+            return (double)p.kw0 / (i == 0 ? 0. : log((double)i));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// one MH step for node v (metropolis_hasting.cc:42-62)
+// ------------------------------------------------------------------------------------------
+template <int RNG>
+__device__ bool mh_step(const SweepParams& p, const Tables& tab, ChainCtx& c, Mt& engine, Mt& gen,
+                        uint32_t v, double T, uint64_t gstep, uint32_t chain_gid) {
+    const int lane = lane_id();
+    const bool type_b = v >= c.na;
+    const uint32_t K = c.K;
+    const uint32_t k_own = type_b ? c.kb : c.ka, k_oth = type_b ? c.ka : c.kb;
+    const uint32_t own_base = type_b ? c.ka : 0, oth_base = type_b ? 0 : c.ka;
+    const uint32_t beg = p.rowptr[v], end = p.rowptr[v + 1];
+    const uint32_t deg = end - beg;
+    const uint32_t r = c.labels[v];
+    const uint32_t r_loc = r - own_base;
+
+    // ---- k_v: neighbour-label histogram over the CSR row (replaces the dense k_[v] row of
+    //      blockmodel.cc:691-700; labels gathered from HBM, counts reduced in LDS) ----
+    for (uint32_t t = lane; t < k_oth; t += kWave) c.hist[t] = 0;
+    __syncthreads();
+    int lab0 = 0;  // label of neighbour `lane` (first chunk), reused by the proposal
+    for (uint32_t j = lane; j < deg; j += kWave) {
+        const uint32_t nb = p.col[beg + j];
+        const int lab = c.labels[nb];
+        if (j < (uint32_t)kWave) lab0 = lab;
+        atomicAdd(&c.hist[lab - (int)oth_base], 1);
+    }
+    __syncthreads();
+
+    // ---- proposal: single_vertex_change, blockmodel.cc:613-637 ----
+    uint32_t s;
+    double u_acc = 0.;
+    if (RNG == RNG_PHILOX) {
+        const U4 A = phx_draw(p.seed, chain_gid, PHX_STEP_A, gstep);
+        const U4 B = phx_draw(p.seed, chain_gid, PHX_STEP_B, gstep);
+        const double u_idx = u53(A.x, A.y), u_R = u53(A.z, A.w), u_tgt = u53(B.x, B.y);
+        u_acc = u53(B.z, B.w);
+        if (k_own == 1) {
+            s = r;
+        } else if (deg == 0) {
+            s = (uint32_t)(u_idx * (double)K);
+            if (s >= K) s = K - 1;
+        } else {
+            uint32_t which = (uint32_t)(u_idx * (double)deg);
+            if (which >= deg) which = deg - 1;
+            const uint32_t t = which < (uint32_t)kWave ? (uint32_t)bcast(lab0, (int)which)
+                                                        : (uint32_t)c.labels[p.col[beg + which]];
+            const int32_t mrt = c.mr[t];
+            const double R_t = c.epsilon * (double)K / (mrt + c.epsilon * (double)K);
+            if (u_R < R_t) {
+                s = (uint32_t)(u_tgt * (double)K);
+                if (s >= K) s = K - 1;
+            } else {
+                // integer inverse CDF over row m[t][.] restricted to v's own type
+                long long x = (long long)(u_tgt * (double)mrt);
+                if (x >= (long long)mrt) x = (long long)mrt - 1;
+                const uint32_t t_loc = t - oth_base;
+                long long carry = 0;
+                s = own_base + k_own - 1;
+                for (uint32_t c0 = 0; c0 < k_own; c0 += kWave) {
+                    const uint32_t i = c0 + lane;
+                    const long long w = i < k_own ? (long long)Mx(c, type_b, i, t_loc) : 0;
+                    const long long cum = carry + wave_inclusive_scan(w);
+                    const unsigned long long hit = __ballot(i < k_own && cum > x);
+                    if (hit) {
+                        s = own_base + c0 + (uint32_t)__ffsll((long long)hit) - 1;
+                        break;
+                    }
+                    carry = __shfl(cum, kWave - 1, kWave);
+                }
+            }
+        }
+    } else {
+        // the reference's draw order: engine for idx / R / uniform target,
+        // `gen` for the discrete draw
+        if (k_own == 1) {
+            s = r;
+        } else if (deg == 0) {
+            s = (uint32_t)(size_t)(engine.canonical() * (double)K);
+        } else {
+            const uint32_t which = (uint32_t)(size_t)(engine.canonical() * (double)deg);
+            const uint32_t t = which < (uint32_t)kWave ? (uint32_t)bcast(lab0, (int)which)
+                                                        : (uint32_t)c.labels[p.col[beg + which]];
+            const int32_t mrt = c.mr[t];
+            const double R_t = c.epsilon * (double)K / (mrt + c.epsilon * (double)K);
+            if (engine.canonical() < R_t) {
+                s = (uint32_t)(size_t)(engine.canonical() * (double)K);
+            } else {
+                // std::discrete_distribution over the full row m_[t][0..K) (random.tcc:2656-2714):
+                // p = w / sum, serial partial sums, last = 1.0, lower_bound(u)
+                const uint32_t t_loc = t - oth_base;
+                const double u = gen.canonical();
+                const double sum = (double)mrt;  // accumulate() of integers is exact
+                double acc = 0.;
+                s = K - 1;
+                bool found = false;
+                for (uint32_t c0 = 0; c0 < K && !found; c0 += kWave) {
+                    const uint32_t g = c0 + lane;
+                    int32_t w = 0;
+                    if (g < K && g >= own_base && g < own_base + k_own) w = Mx(c, type_b, g - own_base, t_loc);
+                    const double pr = (double)w / sum;
+                    double cp = 0.;
+                    const uint32_t cnt = (K - c0) < (uint32_t)kWave ? (K - c0) : (uint32_t)kWave;
+                    for (uint32_t jj = 0; jj < cnt; ++jj) {
+                        const double pj = bcast(pr, (int)jj);
+                        acc = (c0 + jj == 0) ? pj : acc + pj;
+                        if ((uint32_t)lane == jj) cp = acc;
+                    }
+                    if (g == K - 1) cp = 1.0;
+                    const unsigned long long hit = __ballot(g < K && cp >= u);
+                    if (hit) {
+                        s = c0 + (uint32_t)__ffsll((long long)hit) - 1;
+                        found = true;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- transition_ratio, metropolis_hasting.cc:103-192 ----
+    double dS;
+    bool same = (r == s);
+    const bool cross = !same && ((r < c.ka) != (s < c.ka));
+    if (same) {
+        c.accu_r = 1.;  // :109-112
+        dS = 0.;
+    } else if (cross) {
+        dS = INFINITY;  // :121-123, accu_r left stale
+    } else {
+        const uint32_t s_loc = s - own_base;
+        const double Kd = (double)K;
+        const double eps = c.epsilon;
+        double accu0 = 0., accu1 = 0., entropy0 = 0., entropy1 = 0.;
+        for (uint32_t c0 = 0; c0 < k_oth; c0 += kWave) {  // :150-163
+            const uint32_t j = c0 + lane;
+            int k = 0;
+            double A0 = 0., A1 = 0., L1 = 0., L2 = 0., L3 = 0., L4 = 0.;
+            if (j < k_oth) k = c.hist[j];
+            if (k != 0) {
+                const int32_t m_rt = Mx(c, type_b, r_loc, j), m_st = Mx(c, type_b, s_loc, j);
+                const int32_t mr_t = c.mr[oth_base + j];
+                A0 = k * (m_st + eps) / (mr_t + eps * Kd) / (int)deg;
+                A1 = k * (m_rt - k + eps) / (mr_t + eps * Kd) / (int)deg;
+                L1 = lgamma_fast(tab, (long long)m_rt + 1);
+                L2 = lgamma_fast(tab, (long long)m_st + 1);
+                L3 = lgamma_fast(tab, (long long)m_rt - k + 1);
+                L4 = lgamma_fast(tab, (long long)m_st + k + 1);
+            }
+            if (RNG == RNG_PHILOX) {
+                // per-lane partial sums over chunks, reduced by the butterfly below
+                accu0 += A0;
+                accu1 += A1;
+                entropy0 -= L1;
+                entropy0 -= L2;
+                entropy1 -= L3;
+                entropy1 -= L4;
+            } else {
+                // the reference's serial sums in ascending block index
+                const uint32_t cnt = (k_oth - c0) < (uint32_t)kWave ? (k_oth - c0) : (uint32_t)kWave;
+                for (uint32_t jj = 0; jj < cnt; ++jj) {
+                    if (bcast(k, (int)jj) == 0) continue;
+                    accu0 += bcast(A0, (int)jj);
+                    accu1 += bcast(A1, (int)jj);
+                    entropy0 -= bcast(L1, (int)jj);
+                    entropy0 -= bcast(L2, (int)jj);
+                    entropy1 -= bcast(L3, (int)jj);
+                    entropy1 -= bcast(L4, (int)jj);
+                }
+            }
+        }
+        if (RNG == RNG_PHILOX) {
+            accu0 = butterfly_sum(accu0);
+            accu1 = butterfly_sum(accu1);
+            entropy0 = butterfly_sum(entropy0);
+            entropy1 = butterfly_sum(entropy1);
+        }
+        const int ideg = (int)deg;
+        const int m0r = c.mr[r], m1r = m0r - ideg;
+        const int m0s = c.mr[s], m1s = m0s + ideg;
+        const int n_r_r = c.nr[r], n_r_s = c.nr[s];
+        const int eta_r = (int)c.eta[r * c.D + deg], eta_s = (int)c.eta[s * c.D + deg];
+        entropy0 -= -lgamma_fast(tab, (long long)m0r + 1);  // :164-168
+        entropy0 -= -lgamma_fast(tab, (long long)m0s + 1);
+        entropy1 -= -lgamma_fast(tab, (long long)m1r + 1);
+        entropy1 -= -lgamma_fast(tab, (long long)m1s + 1);
+        entropy0 += -lgamma_fast(tab, (long long)eta_r + 1);  // :173-177
+        entropy0 += -lgamma_fast(tab, (long long)eta_s + 1);
+        entropy1 += -lgamma_fast(tab, (long long)eta_r - 1 + 1);
+        entropy1 += -lgamma_fast(tab, (long long)eta_s + 1 + 1);
+        entropy0 += log_q(tab, m0r, n_r_r);  // :179-183
+        entropy0 += log_q(tab, m0s, n_r_s);
+        entropy1 += log_q(tab, m1r, n_r_r - 1);
+        entropy1 += log_q(tab, m1s, n_r_s + 1);
+        c.accu_r = (deg == 0) ? 1. : accu1 / accu0;  // :185-189
+        dS = entropy1 - entropy0;
+    }
+
+    // ---- accept, metropolis_hasting.cc:47-61 ----
+    bool accept;
+    if (T == 0.) {
+        accept = dS < 0;
+    } else {
+        const double a = -1. / T * dS + log(c.accu_r);
+        if (a > 0.) {
+            accept = true;
+        } else {
+            const double u = (RNG == RNG_PHILOX) ? u_acc : engine.canonical();
+            accept = u < exp(a);
+        }
+    }
+    if (!accept) return false;
+
+    // ---- apply_mcmc_moves, blockmodel.cc:461-503 ----
+    if (c.nr[r] - 1 == 0) return false;  // :467-471: a move that empties a block is vetoed after the draw
+    if (same) return true;               // n_r, eta, m updates cancel; entropy_ += 0
+    __syncthreads();                     // all lanes have read nr/mr/eta before lane 0 rewrites them
+    if (lane == 0) {
+        c.nr[r] -= 1;
+        c.nr[s] += 1;
+        c.eta[r * c.D + deg] -= 1;
+        c.eta[s * c.D + deg] += 1;
+        c.mr[r] -= (int)deg;
+        c.mr[s] += (int)deg;
+        c.labels[v] = (uint8_t)s;
+    }
+    {
+        const uint32_t s_loc = s - own_base;
+        for (uint32_t j = lane; j < k_oth; j += kWave) {  // :479-487 (mirror entries are the same cells here)
+            const int k = c.hist[j];
+            if (k != 0) {
+                Mx(c, type_b, r_loc, j) -= k;
+                Mx(c, type_b, s_loc, j) += k;
+            }
+        }
+    }
+    c.cum_dS += dS;  // :500
+    __syncthreads();
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// sweep kernel: metropolis_hasting::anneal (metropolis_hasting.cc:64-101), one wave per chain
+// ------------------------------------------------------------------------------------------
+template <int RNG>
+__global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const uint32_t chain = blockIdx.x;
+    if (chain >= p.n_chains) return;
+    const int lane = lane_id();
+    const uint32_t K = p.ka + p.kb;
+    const uint32_t D = p.maxdeg + 1;
+    const uint32_t S = p.kb | 1u;
+    const uint32_t kmax = p.ka > p.kb ? p.ka : p.kb;
+
+    // carve LDS
+    ChainCtx c;
+    unsigned char* cur = lds_raw;
+    c.mq = (int32_t*)cur;
+    cur += sizeof(int32_t) * p.ka * S;
+    c.mr = (int32_t*)cur;
+    cur += sizeof(int32_t) * K;
+    c.nr = (int32_t*)cur;
+    cur += sizeof(int32_t) * K;
+    c.hist = (int32_t*)cur;
+    cur += sizeof(int32_t) * kmax;
+    uint32_t* eta_g = p.eta + (size_t)chain * K * D;
+    if (p.eta_in_lds) {
+        c.eta = (uint32_t*)cur;
+        cur += sizeof(uint32_t) * K * D;
+    } else {
+        c.eta = eta_g;
+    }
+    Mt engine{nullptr, 624}, gen{nullptr, 624};
+    uint32_t* vl = nullptr;
+    if (RNG == RNG_COMPAT) {
+        engine.mt = (uint32_t*)cur;
+        cur += sizeof(uint32_t) * 624;
+        gen.mt = (uint32_t*)cur;
+        cur += sizeof(uint32_t) * 624;
+        if (p.vlist_in_lds) {
+            vl = (uint32_t*)cur;
+            cur += sizeof(uint32_t) * p.n;
+        } else {
+            vl = p.vlist + (size_t)chain * p.n;
+        }
+    }
+    c.labels = p.labels + (size_t)chain * p.label_stride;
+    c.ka = p.ka;
+    c.kb = p.kb;
+    c.K = K;
+    c.S = S;
+    c.D = D;
+    c.na = p.na;
+    c.epsilon = p.epsilon;
+
+    // load the chain's block state into LDS
+    int32_t* m_g = p.m + (size_t)chain * p.ka * p.kb;
+    int32_t* mr_g = p.m_r + (size_t)chain * K;
+    int32_t* nr_g = p.n_r + (size_t)chain * K;
+    for (uint32_t i = lane; i < p.ka * p.kb; i += kWave) c.mq[(i / p.kb) * S + (i % p.kb)] = m_g[i];
+    for (uint32_t i = lane; i < K; i += kWave) {
+        c.mr[i] = mr_g[i];
+        c.nr[i] = nr_g[i];
+    }
+    if (p.eta_in_lds)
+        for (uint32_t i = lane; i < K * D; i += kWave) c.eta[i] = eta_g[i];
+    ChainScalars* sc = p.scalars + chain;
+    if (RNG == RNG_COMPAT) {
+        const uint32_t* eg = p.mt_engine + (size_t)chain * 624;
+        const uint32_t* gg = p.mt_gen + (size_t)chain * 624;
+        for (uint32_t i = lane; i < 624; i += kWave) {
+            engine.mt[i] = eg[i];
+            gen.mt[i] = gg[i];
+        }
+        engine.idx = (int)sc->engine_idx;
+        gen.idx = (int)sc->gen_idx;
+        if (p.vlist_in_lds) {
+            const uint32_t* vg = p.vlist + (size_t)chain * p.n;
+            for (uint32_t i = lane; i < p.n; i += kWave) vl[i] = vg[i];
+        }
+    }
+    c.cum_dS = sc->cum_dS;
+    c.accu_r = sc->accu_r;
+    uint64_t sweeps_total = sc->sweeps_total;
+    __syncthreads();
+
+    Tables tab{p.lgamma_tab, p.lgamma_size, p.q_tab, p.q_stride};
+    const uint32_t chain_gid = p.first_chain_id + chain;
+    const uint64_t num_nodes = p.n;
+    const uint64_t all_sweeps = p.duration / num_nodes;
+    uint64_t accepted_steps = 0, u = 0, sweeps_done = 0;
+    double entropy_min = INFINITY;  // :75
+    double rate = 0.;
+    bool stopped = false;
+
+    for (uint64_t sweep = 0; sweep < all_sweeps; ++sweep) {
+        Feistel order;
+        if (RNG == RNG_COMPAT) {
+            mt_shuffle(engine, vl, (uint32_t)num_nodes);  // :80
+        } else {
+            order.init(phx_draw(p.seed, chain_gid, PHX_SWEEP_KEY, sweeps_total), (uint32_t)num_nodes);
+        }
+        const uint64_t current_step = num_nodes * sweep;  // :82
+        for (uint64_t vi0 = 0; vi0 < num_nodes; vi0 += kWave) {
+            // each lane evaluates one position of the visit order; steps then run one by one
+            uint32_t v_lane = 0;
+            if (vi0 + lane < num_nodes)
+                v_lane = (RNG == RNG_COMPAT) ? vl[vi0 + lane] : order((uint32_t)(vi0 + lane));
+            const uint32_t cnt = (num_nodes - vi0) < (uint64_t)kWave ? (uint32_t)(num_nodes - vi0) : (uint32_t)kWave;
+            for (uint32_t q = 0; q < cnt; ++q) {
+                const uint32_t v = (uint32_t)__shfl((int)v_lane, (int)q, kWave);
+                const uint64_t vi = vi0 + q;
+                const double T = temperature(p, current_step + vi);  // :84
+                const bool ok = mh_step<RNG>(p, tab, c, engine, gen, v, T, sweeps_total * num_nodes + vi, chain_gid);
+                if (ok) {  // :85-91
+                    ++accepted_steps;
+                    if (c.cum_dS < entropy_min) {
+                        entropy_min = c.cum_dS;
+                        u = 0;
+                    }
+                }
+                if (T < 1.) ++u;  // :92-94
+            }
+        }
+        ++sweeps_total;
+        sweeps_done = sweep + 1;
+        if (u >= p.steps_await) {  // :96-98
+            rate = (double)accepted_steps / (double)((sweep + 1) * num_nodes);
+            stopped = true;
+            break;
+        }
+    }
+    if (!stopped) rate = (double)accepted_steps / (double)p.duration;  // :100
+
+    // store the chain back
+    __syncthreads();
+    for (uint32_t i = lane; i < p.ka * p.kb; i += kWave) m_g[i] = c.mq[(i / p.kb) * S + (i % p.kb)];
+    for (uint32_t i = lane; i < K; i += kWave) {
+        mr_g[i] = c.mr[i];
+        nr_g[i] = c.nr[i];
+    }
+    if (p.eta_in_lds)
+        for (uint32_t i = lane; i < K * D; i += kWave) eta_g[i] = c.eta[i];
+    if (RNG == RNG_COMPAT) {
+        uint32_t* eg = p.mt_engine + (size_t)chain * 624;
+        uint32_t* gg = p.mt_gen + (size_t)chain * 624;
+        for (uint32_t i = lane; i < 624; i += kWave) {
+            eg[i] = engine.mt[i];
+            gg[i] = gen.mt[i];
+        }
+        if (p.vlist_in_lds) {
+            uint32_t* vg = p.vlist + (size_t)chain * p.n;
+            for (uint32_t i = lane; i < p.n; i += kWave) vg[i] = vl[i];
+        }
+    }
+    if (lane == 0) {
+        sc->cum_dS = c.cum_dS;
+        sc->accu_r = c.accu_r;
+        sc->sweeps_total = sweeps_total;
+        sc->last_rate = rate;
+        sc->last_accepted = accepted_steps;
+        sc->last_sweeps = sweeps_done;
+        sc->engine_idx = (uint32_t)engine.idx;
+        sc->gen_idx = (uint32_t)gen.idx;
+    }
+}
+
+template __global__ void sweep_kernel<RNG_PHILOX>(SweepParams);
+template __global__ void sweep_kernel<RNG_COMPAT>(SweepParams);
+
+// ------------------------------------------------------------------------------------------
+// state build: init_bisbm (blockmodel.cc:682-688, compute_n_r :740-746, compute_m :702-714,
+// compute_m_r :716-727, compute_eta_rk :729-738).  One 256-thread workgroup per chain; the
+// a x b quadrant is histogrammed in LDS from the type-a rows of the CSR (the b rows are its
+// transpose), eta / n_r with global atomics on the chain's own (zeroed) arrays.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void state_build_kernel(BuildParams p) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    int32_t* mq = (int32_t*)lds_raw;  // ka*kb
+    const uint32_t chain = blockIdx.x;
+    const uint32_t K = p.ka + p.kb, D = p.maxdeg + 1;
+    const uint8_t* labels = p.labels + (size_t)chain * p.label_stride;
+    int32_t* m_g = p.m + (size_t)chain * p.ka * p.kb;
+    int32_t* mr_g = p.m_r + (size_t)chain * K;
+    int32_t* nr_g = p.n_r + (size_t)chain * K;
+    uint32_t* eta_g = p.eta + (size_t)chain * K * D;
+    for (uint32_t i = threadIdx.x; i < p.ka * p.kb; i += blockDim.x) mq[i] = 0;
+    for (uint32_t i = threadIdx.x; i < K; i += blockDim.x) {
+        mr_g[i] = 0;
+        nr_g[i] = 0;
+    }
+    for (uint32_t i = threadIdx.x; i < K * D; i += blockDim.x) eta_g[i] = 0;
+    __syncthreads();
+    for (uint32_t v = threadIdx.x; v < p.n; v += blockDim.x) {
+        const uint32_t r = labels[v];
+        const uint32_t beg = p.rowptr[v], end = p.rowptr[v + 1];
+        atomicAdd(&nr_g[r], 1);
+        atomicAdd(&eta_g[r * D + (end - beg)], 1u);
+        if (v < p.na) {
+            for (uint32_t e = beg; e < end; ++e) {
+                const uint32_t t = labels[p.col[e]];
+                atomicAdd(&mq[r * p.kb + (t - p.ka)], 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < p.ka * p.kb; i += blockDim.x) {
+        const int32_t x = mq[i];
+        m_g[i] = x;
+        if (x) {
+            atomicAdd(&mr_g[i / p.kb], x);
+            atomicAdd(&mr_g[p.ka + i % p.kb], x);
+        }
+    }
+}
+
+// set_memberships: u32 host labels (staged on device) -> u8, one chain or broadcast to all
+__global__ void labels_broadcast_kernel(const uint32_t* src, uint8_t* labels, size_t label_stride,
+                                        uint32_t n, uint32_t first_chain, uint32_t n_chains) {
+    const uint32_t chain = first_chain + blockIdx.y;
+    if (blockIdx.y >= n_chains) return;
+    uint8_t* dst = labels + (size_t)chain * label_stride;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        dst[i] = (uint8_t)src[i];
+}
+
+__global__ void labels_widen_kernel(const uint8_t* labels, uint32_t* dst, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        dst[i] = labels[i];
+}
+
+// shuffle_bisbm, Philox definition: each type's labels are gathered through a keyed Feistel
+// permutation (block sizes preserved).  grid = (tiles, chains).
+__global__ void shuffle_philox_kernel(ShuffleParams p) {
+    const uint32_t chain = blockIdx.y;
+    const uint8_t* src = p.labels_old + (size_t)chain * p.label_stride;
+    uint8_t* dst = p.labels + (size_t)chain * p.label_stride;
+    const uint32_t gid = p.first_chain_id + chain;
+    const uint32_t epoch = p.scalars[chain].shuffle_epoch;
+    Feistel fa, fb;
+    fa.init(phx_draw(p.seed, gid, PHX_INIT_SHUFFLE, ((uint64_t)0 << 32) | epoch), p.na);
+    fb.init(phx_draw(p.seed, gid, PHX_INIT_SHUFFLE, ((uint64_t)1 << 32) | epoch), p.nb);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += gridDim.x * blockDim.x)
+        dst[i] = i < p.na ? src[fa(i)] : src[p.na + fb(i - p.na)];
+}
+
+__global__ void shuffle_epoch_bump_kernel(ChainScalars* sc, uint32_t n_chains) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_chains) sc[i].shuffle_epoch += 1;
+}
+
+// shuffle_bisbm, compat: two std::shuffle calls on `engine` (blockmodel.cc:673-674)
+__global__ __launch_bounds__(kWave) void shuffle_compat_kernel(ShuffleParams p) {
+    __shared__ uint32_t mt_lds[624];
+    const uint32_t chain = blockIdx.x;
+    const int lane = lane_id();
+    uint32_t* eg = p.mt_engine + (size_t)chain * 624;
+    for (uint32_t i = lane; i < 624; i += kWave) mt_lds[i] = eg[i];
+    __syncthreads();
+    Mt engine{mt_lds, (int)p.scalars[chain].engine_idx};
+    uint8_t* labels = p.labels + (size_t)chain * p.label_stride;
+    mt_shuffle(engine, labels, p.na);
+    mt_shuffle(engine, labels + p.na, p.nb);
+    __syncthreads();
+    for (uint32_t i = lane; i < 624; i += kWave) eg[i] = mt_lds[i];
+    if (lane == 0) p.scalars[chain].engine_idx = (uint32_t)engine.idx;
+}
+
+// ------------------------------------------------------------------------------------------
+// entropy(): the chain-dependent part of blockmodel.cc:753-787 (upper triangle of m, eta, m_r,
+// log_q).  One wave per chain, butterfly reduction.  The chain-independent terms (degrees,
+// multi-edge multiplicities, binomials) are added by the host.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWave) void entropy_kernel(EntropyParams p) {
+    const uint32_t chain = blockIdx.x;
+    const int lane = lane_id();
+    const uint32_t K = p.ka + p.kb, D = p.maxdeg + 1;
+    Tables tab{p.lgamma_tab, p.lgamma_size, p.q_tab, p.q_stride};
+    const int32_t* m_g = p.m + (size_t)chain * p.ka * p.kb;
+    const int32_t* mr_g = p.m_r + (size_t)chain * K;
+    const int32_t* nr_g = p.n_r + (size_t)chain * K;
+    const uint32_t* eta_g = p.eta + (size_t)chain * K * D;
+    double ent = 0.;
+    // m_[r][s], s > r: the a x b quadrant covers every non-zero upper-triangle cell; the zero cells of
+    // the same-type blocks contribute lgamma(1) = 0
+    for (uint32_t i = lane; i < p.ka * p.kb; i += kWave) ent -= lgamma_fast(tab, (long long)m_g[i] + 1);
+    for (uint32_t i = lane; i < K * D; i += kWave) ent -= lgamma_fast(tab, (long long)eta_g[i] + 1);
+    for (uint32_t r = lane; r < K; r += kWave) {
+        ent += lgamma_fast(tab, (long long)mr_g[r] + 1);
+        ent += log_q(tab, mr_g[r], nr_g[r]);
+    }
+    ent = butterfly_sum(ent);
+    if (lane == 0) p.out[chain] = ent;
+}
+
+// ------------------------------------------------------------------------------------------
+// marginals: counts[v][block index within v's type] += #chains whose label of v is that block.
+// Thread = node; labels are read coalesced along the node axis of the chain-major array.
+// ------------------------------------------------------------------------------------------
+__global__ void marginals_kernel(MarginalParams p) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= p.n) return;
+    const uint32_t base = v < p.na ? 0 : p.ka;
+    uint32_t* row = p.counts + (size_t)v * p.kmax;
+    for (uint32_t c = 0; c < p.n_chains; ++c) {
+        const uint32_t lab = p.labels[(size_t)c * p.label_stride + v];
+        row[lab - base] += 1;
+    }
+}
+
+__global__ void log_q_probe_kernel(Tables tab, const int32_t* n, const int32_t* k, size_t count, double* out) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < count) out[i] = log_q(tab, n[i], k[i]);
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers (called from the host runtime)
+// ------------------------------------------------------------------------------------------
+hipError_t launch_sweep(const SweepParams& p, int rng_mode, size_t lds_bytes, hipStream_t stream) {
+    const dim3 grid(p.n_chains), block(kWave);
+    if (rng_mode == RNG_COMPAT) {
+        hipError_t e = hipFuncSetAttribute((const void*)sweep_kernel<RNG_COMPAT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(sweep_kernel<RNG_COMPAT>, grid, block, lds_bytes, stream, p);
+    } else {
+        hipError_t e = hipFuncSetAttribute((const void*)sweep_kernel<RNG_PHILOX>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(sweep_kernel<RNG_PHILOX>, grid, block, lds_bytes, stream, p);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_state_build(const BuildParams& p, hipStream_t stream) {
+    const size_t lds = sizeof(int32_t) * p.ka * p.kb;
+    hipError_t e = hipFuncSetAttribute((const void*)state_build_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(state_build_kernel, dim3(p.n_chains), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_labels_broadcast(const uint32_t* src, uint8_t* labels, size_t label_stride, uint32_t n,
+                                   uint32_t first_chain, uint32_t n_chains, hipStream_t stream) {
+    const uint32_t tiles = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
+    hipLaunchKernelGGL(labels_broadcast_kernel, dim3(tiles ? tiles : 1, n_chains), dim3(256), 0, stream, src,
+                       labels, label_stride, n, first_chain, n_chains);
+    return hipGetLastError();
+}
+
+hipError_t launch_labels_widen(const uint8_t* labels, uint32_t* dst, uint32_t n, hipStream_t stream) {
+    const uint32_t tiles = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
+    hipLaunchKernelGGL(labels_widen_kernel, dim3(tiles ? tiles : 1), dim3(256), 0, stream, labels, dst, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_shuffle(const ShuffleParams& p, int rng_mode, hipStream_t stream) {
+    if (rng_mode == RNG_COMPAT) {
+        hipLaunchKernelGGL(shuffle_compat_kernel, dim3(p.n_chains), dim3(kWave), 0, stream, p);
+    } else {
+        const uint32_t tiles = (p.n + 255) / 256 < 1024 ? (p.n + 255) / 256 : 1024;
+        hipLaunchKernelGGL(shuffle_philox_kernel, dim3(tiles ? tiles : 1, p.n_chains), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(shuffle_epoch_bump_kernel, dim3((p.n_chains + 255) / 256), dim3(256), 0, stream,
+                           p.scalars, p.n_chains);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_entropy(const EntropyParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(entropy_kernel, dim3(p.n_chains), dim3(kWave), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_marginals(const MarginalParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(marginals_kernel, dim3((p.n + 255) / 256), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_log_q_probe(const Tables& tab, const int32_t* n, const int32_t* k, size_t count, double* out,
+                              hipStream_t stream) {
+    hipLaunchKernelGGL(log_q_probe_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, tab, n, k,
+                       count, out);
+    return hipGetLastError();
+}
+
+}  // namespace bisbm

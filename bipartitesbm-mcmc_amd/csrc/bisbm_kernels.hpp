@@ -1,0 +1,114 @@
+// bisbm_kernels.hpp -- kernel parameter blocks and launcher prototypes shared by
+// bisbm_kernels.hip (device) and bisbm_runtime.hip (host side of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bisbm_device.hpp"
+
+namespace bisbm {
+
+// Per-chain scalar state kept in HBM between kernels.
+struct ChainScalars {
+    double cum_dS;          // blockmodel_t::entropy_ (blockmodel.hh:100): running sum of accepted dS
+    double accu_r;          // metropolis_hasting::accu_r_ (metropolis_hasting.hh:28), survives anneal calls
+    double last_rate;       // return value of the last anneal
+    uint64_t sweeps_total;  // Philox counter: sweeps executed over the chain's lifetime
+    uint64_t last_accepted;
+    uint64_t last_sweeps;
+    uint32_t shuffle_epoch;  // Philox counter: shuffle_bisbm calls so far
+    uint32_t engine_idx;     // std::mt19937 positions (compat mode)
+    uint32_t gen_idx;
+    uint32_t pad_;
+};
+
+struct SweepParams {
+    // graph (shared by all chains)
+    const uint32_t* rowptr;
+    const uint32_t* col;
+    uint32_t n, na, nb, ka, kb, maxdeg;
+    double epsilon;
+    // chains
+    uint32_t n_chains, first_chain_id;
+    uint8_t* labels;
+    size_t label_stride;
+    uint32_t* vlist;  // compat: [chain][n]
+    int32_t* m;       // [chain][ka*kb]
+    int32_t* m_r;     // [chain][K]
+    int32_t* n_r;     // [chain][K]
+    uint32_t* eta;    // [chain][K*(maxdeg+1)]
+    ChainScalars* scalars;
+    uint32_t* mt_engine;  // compat: [chain][624]
+    uint32_t* mt_gen;
+    // tables
+    const double* lgamma_tab;
+    uint64_t lgamma_size;
+    const double* q_tab;
+    uint32_t q_stride;
+    const double* T_tab;  // host-evaluated temperatures for the pow/log schedules
+    uint64_t T_len;
+    int T_zero_after;
+    // schedule / run
+    int schedule;
+    float kw0, kw1;
+    uint64_t duration, steps_await;
+    uint64_t seed;
+    int eta_in_lds;
+    int vlist_in_lds;
+};
+
+struct BuildParams {
+    const uint32_t* rowptr;
+    const uint32_t* col;
+    uint32_t n, na, ka, kb, maxdeg, n_chains;
+    const uint8_t* labels;
+    size_t label_stride;
+    int32_t* m;
+    int32_t* m_r;
+    int32_t* n_r;
+    uint32_t* eta;
+};
+
+struct ShuffleParams {
+    uint32_t n, na, nb, n_chains, first_chain_id;
+    uint64_t seed;
+    uint8_t* labels;
+    const uint8_t* labels_old;  // Philox: snapshot the gather reads from
+    size_t label_stride;
+    ChainScalars* scalars;
+    uint32_t* mt_engine;
+};
+
+struct EntropyParams {
+    uint32_t ka, kb, maxdeg, n_chains;
+    const int32_t* m;
+    const int32_t* m_r;
+    const int32_t* n_r;
+    const uint32_t* eta;
+    const double* lgamma_tab;
+    uint64_t lgamma_size;
+    const double* q_tab;
+    uint32_t q_stride;
+    double* out;
+};
+
+struct MarginalParams {
+    uint32_t n, na, ka, kmax, n_chains;
+    const uint8_t* labels;
+    size_t label_stride;
+    uint32_t* counts;
+};
+
+hipError_t launch_sweep(const SweepParams& p, int rng_mode, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_state_build(const BuildParams& p, hipStream_t stream);
+hipError_t launch_labels_broadcast(const uint32_t* src, uint8_t* labels, size_t label_stride, uint32_t n,
+                                   uint32_t first_chain, uint32_t n_chains, hipStream_t stream);
+hipError_t launch_labels_widen(const uint8_t* labels, uint32_t* dst, uint32_t n, hipStream_t stream);
+hipError_t launch_shuffle(const ShuffleParams& p, int rng_mode, hipStream_t stream);
+hipError_t launch_entropy(const EntropyParams& p, hipStream_t stream);
+hipError_t launch_marginals(const MarginalParams& p, hipStream_t stream);
+hipError_t launch_log_q_probe(const Tables& tab, const int32_t* n, const int32_t* k, size_t count, double* out,
+                              hipStream_t stream);
+
+}  // namespace bisbm

@@ -1,0 +1,783 @@
+// bisbm_runtime.hip -- host side of the C ABI (include/bisbm.h): handle, device memory, host-built
+// numeric tables, kernel launches.  No CPU compute path exists here: every operation on chain state
+// runs in a HIP kernel (bisbm_kernels.hip), and bisbm_create fails without a device.
+//
+// Reference lines cited as <file>:<line> relative to /root/reference/src.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "../../include/bisbm.h"
+#include "bisbm_kernels.hpp"
+
+using namespace bisbm;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// ------------------------------------------------------------------------------------------
+// host-built tables (the reference builds the same tables on the host at construction:
+// blockmodel.cc:47-48 -> support/cache.cc:64-91, support/int_part.cc:34-51)
+// ------------------------------------------------------------------------------------------
+struct HostTables {
+    std::vector<double> lg;  // lg[i] = lgamma(i), lg[0] = +inf
+    std::vector<double> q;   // (10001) x (kcap+1)
+    uint32_t kcap = 0;
+};
+
+std::mutex g_tab_mu;
+std::map<std::pair<uint64_t, uint32_t>, std::shared_ptr<HostTables>> g_tab_cache;
+
+double log_sum(double a, double b) {  // int_part.cc:30-32
+    return std::max(a, b) + std::log1p(std::exp(-std::fabs(a - b)));
+}
+
+void fill_lgamma(std::vector<double>& lg) {  // cache.cc:64-79
+    const size_t n = lg.size();
+    lg[0] = INFINITY;
+    unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (n < (1u << 16)) nt = 1;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) {
+        th.emplace_back([&, t] {
+            int sign;
+            for (size_t i = 1 + t; i < n; i += nt) lg[i] = lgamma_r((double)i, &sign);
+        });
+    }
+    for (auto& x : th) x.join();
+}
+
+// int_part.cc:34-51 with the columns cut at kcap (column k only depends on columns <= k).  Cells
+// the reference never writes (k > n) stay -inf and are read as such by the recurrence.
+// Rows are processed in blocks: inside a block columns < B are filled row by row (a cell (n,k)
+// reads (n-k,k), which can lie in the same block only when k < B); the remaining columns of the
+// block's rows are independent of each other and are split over threads.  The evaluation order per
+// cell is unchanged, so the values equal the serial recurrence bit for bit.
+void fill_q(std::vector<double>& q, uint32_t kcap) {
+    const size_t stride = (size_t)kcap + 1;
+    std::fill(q.begin(), q.end(), -INFINITY);
+    const size_t B = 128;
+    auto cell = [&](size_t n, size_t k) {
+        double* row = q.data() + n * stride;
+        row[k] = log_sum(row[k], row[k - 1]);
+        if (n > k) row[k] = log_sum(row[k], q[(n - k) * stride + k]);
+    };
+    unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (kcap < 2048) nt = 1;
+    for (size_t n0 = 1; n0 <= (size_t)kQNmax; n0 += B) {
+        const size_t n1 = std::min<size_t>(n0 + B, (size_t)kQNmax + 1);
+        for (size_t n = n0; n < n1; ++n) {
+            q[n * stride + 1] = 0;
+            const size_t kmax = std::min<size_t>(std::min<size_t>(n, kcap), B - 1);
+            for (size_t k = 2; k <= kmax; ++k) cell(n, k);
+        }
+        auto rest = [&](size_t lo, size_t hi) {
+            for (size_t n = lo; n < hi; ++n) {
+                const size_t kmax = std::min<size_t>(n, kcap);
+                for (size_t k = B; k <= kmax; ++k) cell(n, k);
+            }
+        };
+        if (nt == 1 || n1 <= B) {
+            rest(n0, n1);
+        } else {
+            std::vector<std::thread> th;
+            const size_t per = (n1 - n0 + nt - 1) / nt;
+            for (unsigned t = 0; t < nt; ++t) {
+                const size_t lo = n0 + t * per, hi = std::min(n1, lo + per);
+                if (lo < hi) th.emplace_back(rest, lo, hi);
+            }
+            for (auto& x : th) x.join();
+        }
+    }
+}
+
+std::shared_ptr<HostTables> get_tables(uint64_t lg_size, uint32_t kcap) {
+    std::lock_guard<std::mutex> lk(g_tab_mu);
+    for (auto& kv : g_tab_cache)
+        if (kv.first.first >= lg_size && kv.first.second >= kcap && kv.first.second <= 2 * kcap + 64 &&
+            kv.first.first <= 2 * lg_size + 4096)
+            return kv.second;
+    auto t = std::make_shared<HostTables>();
+    t->lg.resize(lg_size);
+    fill_lgamma(t->lg);
+    t->kcap = kcap;
+    t->q.resize((size_t)(kQNmax + 1) * ((size_t)kcap + 1));
+    fill_q(t->q, kcap);
+    if (g_tab_cache.size() > 4) g_tab_cache.clear();
+    g_tab_cache[{lg_size, kcap}] = t;
+    return t;
+}
+
+double h_lgamma_fast(const HostTables& t, uint64_t x) {  // cache.hh:82-93
+    if (x < t.lg.size()) return t.lg[x];
+    if (x == 0) return INFINITY;
+    int sign;
+    return lgamma_r((double)x, &sign);
+}
+
+double h_lbinom_fast(const HostTables& t, uint64_t N, uint64_t k) {  // util.hh:41-47
+    if (N == 0 || k == 0 || k > N) return 0;
+    return (h_lgamma_fast(t, N + 1) - h_lgamma_fast(t, k + 1)) - h_lgamma_fast(t, N - k + 1);
+}
+
+// metropolis_hasting.cc:10-13,20-23 evaluated with the host libm for the first `len` steps
+std::vector<double> schedule_table(int schedule, float kw0, float kw1, uint64_t len, int* zero_after) {
+    std::vector<double> T;
+    *zero_after = 0;
+    T.reserve((size_t)std::min<uint64_t>(len, 1u << 16));
+    for (uint64_t t = 0; t < len; ++t) {
+        double v;
+        if (schedule == SCHED_EXPONENTIAL) {
+            v = (double)kw0 * std::pow((double)kw1, (double)t);
+        } else {
+            const float x = (float)t + kw1;
+            const size_t i = (size_t)x;
+            v = (double)kw0 / (i == 0 ? 0. : std::log((double)i));
+        }
+        T.push_back(v);
+        if (schedule == SCHED_EXPONENTIAL && v == 0. && kw1 < 1.f && kw1 >= 0.f) {
+            *zero_after = 1;  // pow is monotone here: every later step is 0 as well
+            break;
+        }
+    }
+    return T;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// the handle
+// ------------------------------------------------------------------------------------------
+struct bisbm_engine {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    // shape
+    uint64_t n = 0, na = 0, nb = 0, num_edges = 0, nnz = 0;
+    uint32_t ka = 0, kb = 0, K = 0, maxdeg = 0, n_chains = 0, first_chain_id = 0;
+    double epsilon = 0;
+    int rng_mode = 0;
+    uint64_t seed = 0, gen_seed = 0;
+    bool state_ready = false;
+    // device memory
+    uint32_t* d_rowptr = nullptr;
+    uint32_t* d_col = nullptr;
+    uint8_t* d_labels = nullptr;
+    uint8_t* d_labels_tmp = nullptr;
+    size_t label_stride = 0;
+    uint32_t* d_vlist = nullptr;
+    int32_t* d_m = nullptr;
+    int32_t* d_m_r = nullptr;
+    int32_t* d_n_r = nullptr;
+    uint32_t* d_eta = nullptr;
+    ChainScalars* d_scalars = nullptr;
+    uint32_t* d_mt_engine = nullptr;
+    uint32_t* d_mt_gen = nullptr;
+    double* d_lgamma = nullptr;
+    double* d_q = nullptr;
+    double* d_T = nullptr;
+    size_t d_T_cap = 0;
+    double* d_tmp_f64 = nullptr;  // n_chains doubles
+    uint32_t* d_stage_u32 = nullptr;  // n uint32 staging
+    uint32_t* d_counts = nullptr;     // internal marginal buffer n*kmax
+    std::shared_ptr<HostTables> tab;
+    uint32_t q_stride = 0;
+    // chain-independent part of entropy()
+    double ent_deg = 0, ent_multi = 0;
+    // last sweep timing
+    double last_kernel_ms = 0;
+    uint64_t last_updates = 0;
+};
+
+namespace {
+
+int fail(bisbm_engine* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h)
+        h->err = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) return fail((h), BISBM_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+hipError_t dalloc(T** p, size_t count) {
+    return hipMalloc((void**)p, sizeof(T) * std::max<size_t>(count, 1));
+}
+
+void free_all(bisbm_engine* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    void* ptrs[] = {h->d_rowptr, h->d_col,       h->d_labels, h->d_labels_tmp, h->d_vlist,     h->d_m,
+                    h->d_m_r,    h->d_n_r,       h->d_eta,    h->d_scalars,    h->d_mt_engine, h->d_mt_gen,
+                    h->d_lgamma, h->d_q,         h->d_T,      h->d_tmp_f64,    h->d_stage_u32, h->d_counts};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+}
+
+void mt_seed_host(uint32_t* mt, uint64_t seed) {  // std::mt19937(seed): seed mod 2^32
+    mt[0] = (uint32_t)seed;
+    for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+}
+
+int rebuild_state(bisbm_engine* h) {
+    BuildParams bp{};
+    bp.rowptr = h->d_rowptr;
+    bp.col = h->d_col;
+    bp.n = (uint32_t)h->n;
+    bp.na = (uint32_t)h->na;
+    bp.ka = h->ka;
+    bp.kb = h->kb;
+    bp.maxdeg = h->maxdeg;
+    bp.n_chains = h->n_chains;
+    bp.labels = h->d_labels;
+    bp.label_stride = h->label_stride;
+    bp.m = h->d_m;
+    bp.m_r = h->d_m_r;
+    bp.n_r = h->d_n_r;
+    bp.eta = h->d_eta;
+    HIPCHK(h, launch_state_build(bp, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->state_ready = true;
+    return BISBM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bisbm_abi_version(void) { return BISBM_ABI_VERSION; }
+
+const char* bisbm_last_error(bisbm_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int bisbm_create(bisbm_handle* out, uint64_t n, uint64_t na, uint64_t nb, const uint64_t* rowptr,
+                 const uint32_t* col, uint32_t ka, uint32_t kb, double epsilon, uint32_t n_chains,
+                 uint32_t first_chain_id, int device, int rng_mode, uint64_t seed, uint64_t gen_seed) {
+    if (!out) return fail(nullptr, BISBM_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!rowptr || (!col && rowptr[n] != 0)) return fail(nullptr, BISBM_ERR_INVALID_ARG, "rowptr/col is NULL");
+    if (n == 0 || na + nb != n) return fail(nullptr, BISBM_ERR_INVALID_ARG, "na + nb must equal n > 0");
+    if (ka == 0 || kb == 0) return fail(nullptr, BISBM_ERR_INVALID_ARG, "ka and kb must be >= 1");
+    if (ka + kb > 256) return fail(nullptr, BISBM_ERR_UNSUPPORTED, "ka + kb = %u > 256 (labels are stored as uint8)", ka + kb);
+    if (n_chains == 0) return fail(nullptr, BISBM_ERR_INVALID_ARG, "n_chains must be >= 1");
+    if (rng_mode != BISBM_RNG_PHILOX && rng_mode != BISBM_RNG_MT19937_COMPAT)
+        return fail(nullptr, BISBM_ERR_INVALID_ARG, "unknown rng_mode %d", rng_mode);
+    if (n >= 0xFFFFFFFFull || rowptr[n] >= 0xFFFFFFFFull)
+        return fail(nullptr, BISBM_ERR_UNSUPPORTED, "more than 2^32-1 nodes or adjacency entries");
+    if (rowptr[0] != 0) return fail(nullptr, BISBM_ERR_INVALID_ARG, "rowptr[0] != 0");
+    const uint64_t nnz = rowptr[n];
+    if (nnz % 2) return fail(nullptr, BISBM_ERR_INVALID_ARG, "odd number of adjacency entries");
+    uint32_t maxdeg = 0;
+    for (uint64_t v = 0; v < n; ++v) {
+        if (rowptr[v + 1] < rowptr[v]) return fail(nullptr, BISBM_ERR_INVALID_ARG, "rowptr is not monotone");
+        maxdeg = std::max<uint32_t>(maxdeg, (uint32_t)(rowptr[v + 1] - rowptr[v]));
+        const bool vb = v >= na;
+        for (uint64_t e = rowptr[v]; e < rowptr[v + 1]; ++e) {
+            if (col[e] >= n) return fail(nullptr, BISBM_ERR_NOT_BIPARTITE, "neighbour id %u >= n", col[e]);
+            if ((col[e] >= na) == vb)
+                return fail(nullptr, BISBM_ERR_NOT_BIPARTITE, "edge (%llu,%u) joins two nodes of one type",
+                            (unsigned long long)v, col[e]);
+        }
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, BISBM_ERR_NO_DEVICE, "no HIP device: this engine has no CPU path");
+    if (device < 0 || device >= ndev) return fail(nullptr, BISBM_ERR_NO_DEVICE, "device %d out of range (%d devices)", device, ndev);
+
+    std::unique_ptr<bisbm_engine> hp(new bisbm_engine());
+    bisbm_engine* h = hp.get();
+    h->device = device;
+    h->n = n;
+    h->na = na;
+    h->nb = nb;
+    h->nnz = nnz;
+    h->num_edges = nnz / 2;
+    h->ka = ka;
+    h->kb = kb;
+    h->K = ka + kb;
+    h->maxdeg = maxdeg;
+    h->n_chains = n_chains;
+    h->first_chain_id = first_chain_id;
+    h->epsilon = epsilon;
+    h->rng_mode = rng_mode;
+    h->seed = seed;
+    h->gen_seed = gen_seed;
+    h->label_stride = (n + 255) & ~(uint64_t)255;
+
+    auto bail = [&](int code) {
+        g_create_error = h->err;
+        free_all(h);
+        return code;
+    };
+#define CCHK(expr)                                                                      \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            fail(h, BISBM_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));             \
+            return bail(BISBM_ERR_HIP);                                                 \
+        }                                                                               \
+    } while (0)
+
+    CCHK(hipSetDevice(device));
+    CCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    CCHK(hipEventCreate(&h->ev0));
+    CCHK(hipEventCreate(&h->ev1));
+
+    // tables: lgamma covers every index the sweep and entropy() can touch
+    // (cache.cc:86-91 sizes it 2E+1 and grows on demand; the values are lgamma(i) either way)
+    uint64_t lg_size = 2 * h->num_edges + 2;
+    lg_size = std::max<uint64_t>(lg_size, n + 3);
+    lg_size = std::max<uint64_t>(lg_size, (uint64_t)ka * kb + h->num_edges + 2);
+    const uint32_t kcap = (uint32_t)std::min<uint64_t>(kQNmax, std::max(na, nb) + 1);
+    h->tab = get_tables(lg_size, std::max<uint32_t>(kcap, 2));
+    h->q_stride = h->tab->kcap + 1;
+
+    const size_t C = n_chains, K = h->K, D = (size_t)maxdeg + 1;
+    CCHK(dalloc(&h->d_rowptr, n + 1));
+    CCHK(dalloc(&h->d_col, nnz));
+    CCHK(dalloc(&h->d_labels, C * h->label_stride));
+    CCHK(dalloc(&h->d_m, C * ka * kb));
+    CCHK(dalloc(&h->d_m_r, C * K));
+    CCHK(dalloc(&h->d_n_r, C * K));
+    CCHK(dalloc(&h->d_eta, C * K * D));
+    CCHK(dalloc(&h->d_scalars, C));
+    CCHK(dalloc(&h->d_lgamma, h->tab->lg.size()));
+    CCHK(dalloc(&h->d_q, h->tab->q.size()));
+    CCHK(dalloc(&h->d_tmp_f64, C));
+    CCHK(dalloc(&h->d_stage_u32, n));
+    if (rng_mode == BISBM_RNG_MT19937_COMPAT) {
+        CCHK(dalloc(&h->d_vlist, C * n));
+        CCHK(dalloc(&h->d_mt_engine, C * 624));
+        CCHK(dalloc(&h->d_mt_gen, C * 624));
+    } else {
+        CCHK(dalloc(&h->d_labels_tmp, C * h->label_stride));
+    }
+
+    {
+        std::vector<uint32_t> rp32(n + 1);
+        for (uint64_t v = 0; v <= n; ++v) rp32[v] = (uint32_t)rowptr[v];
+        CCHK(hipMemcpy(h->d_rowptr, rp32.data(), sizeof(uint32_t) * (n + 1), hipMemcpyHostToDevice));
+        if (nnz) CCHK(hipMemcpy(h->d_col, col, sizeof(uint32_t) * nnz, hipMemcpyHostToDevice));
+        CCHK(hipMemcpy(h->d_lgamma, h->tab->lg.data(), sizeof(double) * h->tab->lg.size(), hipMemcpyHostToDevice));
+        CCHK(hipMemcpy(h->d_q, h->tab->q.data(), sizeof(double) * h->tab->q.size(), hipMemcpyHostToDevice));
+        CCHK(hipMemset(h->d_labels, 0, C * h->label_stride));
+        std::vector<ChainScalars> sc(C);
+        for (auto& s : sc) {
+            std::memset(&s, 0, sizeof(s));
+            s.engine_idx = 624;
+            s.gen_idx = 624;
+        }
+        CCHK(hipMemcpy(h->d_scalars, sc.data(), sizeof(ChainScalars) * C, hipMemcpyHostToDevice));
+        if (rng_mode == BISBM_RNG_MT19937_COMPAT) {
+            std::vector<uint32_t> st(C * 624), vl(C * n);
+            for (size_t c = 0; c < C; ++c) mt_seed_host(&st[c * 624], seed + first_chain_id + c);
+            CCHK(hipMemcpy(h->d_mt_engine, st.data(), sizeof(uint32_t) * st.size(), hipMemcpyHostToDevice));
+            for (size_t c = 0; c < C; ++c) mt_seed_host(&st[c * 624], gen_seed + first_chain_id + c);
+            CCHK(hipMemcpy(h->d_mt_gen, st.data(), sizeof(uint32_t) * st.size(), hipMemcpyHostToDevice));
+            for (size_t c = 0; c < C; ++c)
+                for (uint64_t v = 0; v < n; ++v) vl[c * n + v] = (uint32_t)v;  // blockmodel.cc:41
+            CCHK(hipMemcpy(h->d_vlist, vl.data(), sizeof(uint32_t) * vl.size(), hipMemcpyHostToDevice));
+        }
+    }
+#undef CCHK
+
+    // chain-independent terms of entropy() (blockmodel.cc:755-757,772-779), reference order
+    {
+        double ent = 0;
+        for (uint64_t v = 0; v < n; ++v) ent -= h_lgamma_fast(*h->tab, (rowptr[v + 1] - rowptr[v]) + 1);
+        h->ent_deg = ent;
+        double mul = 0;
+        std::vector<uint32_t> tmp;
+        for (uint64_t y = 0; y < n; ++y) {
+            const uint64_t d = rowptr[y + 1] - rowptr[y];
+            if (d < 2) continue;
+            tmp.assign(col + rowptr[y], col + rowptr[y + 1]);
+            std::sort(tmp.begin(), tmp.end());
+            for (size_t i = 0; i < tmp.size();) {
+                size_t j = i;
+                while (j < tmp.size() && tmp[j] == tmp[i]) ++j;
+                if (j - i > 1 && y > tmp[i]) mul += h_lgamma_fast(*h->tab, (j - i) + 1);
+                i = j;
+            }
+        }
+        h->ent_multi = mul;
+    }
+    *out = hp.release();
+    return BISBM_OK;
+}
+
+int bisbm_destroy(bisbm_handle h) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    free_all(h);
+    delete h;
+    return BISBM_OK;
+}
+
+int bisbm_set_stream(bisbm_handle h, void* hip_stream) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return BISBM_OK;
+}
+
+int bisbm_set_memberships(bisbm_handle h, int64_t chain, const uint32_t* labels) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!labels) return fail(h, BISBM_ERR_INVALID_ARG, "labels is NULL");
+    if (chain != BISBM_ALL_CHAINS && (chain < 0 || chain >= (int64_t)h->n_chains))
+        return fail(h, BISBM_ERR_INVALID_ARG, "chain %lld out of range", (long long)chain);
+    for (uint64_t v = 0; v < h->n; ++v) {
+        const uint32_t b = labels[v];
+        const bool ok = v < h->na ? b < h->ka : (b >= h->ka && b < h->K);
+        if (!ok) return fail(h, BISBM_ERR_INVALID_ARG, "label %u of node %llu is not a block of the node's type", b, (unsigned long long)v);
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h->d_stage_u32, labels, sizeof(uint32_t) * h->n, hipMemcpyHostToDevice, h->stream));
+    const uint32_t first = chain == BISBM_ALL_CHAINS ? 0 : (uint32_t)chain;
+    const uint32_t cnt = chain == BISBM_ALL_CHAINS ? h->n_chains : 1;
+    HIPCHK(h, launch_labels_broadcast(h->d_stage_u32, h->d_labels, h->label_stride, (uint32_t)h->n, first, cnt, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->state_ready = false;
+    return BISBM_OK;
+}
+
+int bisbm_init(bisbm_handle h) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    return rebuild_state(h);
+}
+
+int bisbm_shuffle(bisbm_handle h) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    ShuffleParams sp{};
+    sp.n = (uint32_t)h->n;
+    sp.na = (uint32_t)h->na;
+    sp.nb = (uint32_t)h->nb;
+    sp.n_chains = h->n_chains;
+    sp.first_chain_id = h->first_chain_id;
+    sp.seed = h->seed;
+    sp.labels = h->d_labels;
+    sp.labels_old = h->d_labels_tmp;
+    sp.label_stride = h->label_stride;
+    sp.scalars = h->d_scalars;
+    sp.mt_engine = h->d_mt_engine;
+    if (h->rng_mode == BISBM_RNG_PHILOX)
+        HIPCHK(h, hipMemcpyAsync(h->d_labels_tmp, h->d_labels, (size_t)h->n_chains * h->label_stride,
+                                 hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, launch_shuffle(sp, h->rng_mode, h->stream));
+    return rebuild_state(h);
+}
+
+int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t duration_steps,
+                 uint64_t steps_await, double* acc_rate_out) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!kwargs) return fail(h, BISBM_ERR_INVALID_ARG, "kwargs is NULL");
+    if (schedule < BISBM_SCHED_EXPONENTIAL || schedule > BISBM_SCHED_ABRUPT_COOL)
+        return fail(h, BISBM_ERR_INVALID_ARG, "unknown schedule %d", schedule);
+    if (!h->state_ready) return fail(h, BISBM_ERR_STATE, "call bisbm_init or bisbm_shuffle before bisbm_anneal");
+    HIPCHK(h, hipSetDevice(h->device));
+
+    SweepParams p{};
+    p.rowptr = h->d_rowptr;
+    p.col = h->d_col;
+    p.n = (uint32_t)h->n;
+    p.na = (uint32_t)h->na;
+    p.nb = (uint32_t)h->nb;
+    p.ka = h->ka;
+    p.kb = h->kb;
+    p.maxdeg = h->maxdeg;
+    p.epsilon = h->epsilon;
+    p.n_chains = h->n_chains;
+    p.first_chain_id = h->first_chain_id;
+    p.labels = h->d_labels;
+    p.label_stride = h->label_stride;
+    p.vlist = h->d_vlist;
+    p.m = h->d_m;
+    p.m_r = h->d_m_r;
+    p.n_r = h->d_n_r;
+    p.eta = h->d_eta;
+    p.scalars = h->d_scalars;
+    p.mt_engine = h->d_mt_engine;
+    p.mt_gen = h->d_mt_gen;
+    p.lgamma_tab = h->d_lgamma;
+    p.lgamma_size = h->tab->lg.size();
+    p.q_tab = h->d_q;
+    p.q_stride = h->q_stride;
+    p.schedule = schedule;
+    p.kw0 = kwargs[0];
+    p.kw1 = kwargs[1];
+    p.duration = duration_steps;
+    p.steps_await = steps_await;
+    p.seed = h->seed;
+
+    // temperatures of the pow/log schedules are evaluated with the host libm (the reference's own)
+    p.T_tab = nullptr;
+    p.T_len = 0;
+    p.T_zero_after = 0;
+    if (schedule == BISBM_SCHED_EXPONENTIAL || schedule == BISBM_SCHED_LOGARITHMIC) {
+        const uint64_t cap = 1ull << 22;
+        int zero_after = 0;
+        std::vector<double> T = schedule_table(schedule, p.kw0, p.kw1, std::min(duration_steps, cap), &zero_after);
+        if (T.size() > h->d_T_cap) {
+            if (h->d_T) (void)hipFree(h->d_T);
+            h->d_T = nullptr;
+            HIPCHK(h, dalloc(&h->d_T, T.size()));
+            h->d_T_cap = T.size();
+        }
+        if (!T.empty())
+            HIPCHK(h, hipMemcpyAsync(h->d_T, T.data(), sizeof(double) * T.size(), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        p.T_tab = h->d_T;
+        p.T_len = T.size();
+        p.T_zero_after = zero_after;
+    }
+
+    // LDS plan: m quadrant (odd row stride), m_r, n_r, k_v histogram; eta when it leaves room for
+    // four chains per CU; compat adds the two mt19937 states and (small graphs) the visit list
+    const size_t K = h->K, D = (size_t)h->maxdeg + 1, S = h->kb | 1u;
+    size_t lds = sizeof(int32_t) * (h->ka * S + 2 * K + std::max(h->ka, h->kb));
+    const size_t eta_bytes = sizeof(uint32_t) * K * D;
+    p.eta_in_lds = (lds + eta_bytes <= 36 * 1024) ? 1 : 0;
+    if (p.eta_in_lds) lds += eta_bytes;
+    p.vlist_in_lds = 0;
+    if (h->rng_mode == BISBM_RNG_MT19937_COMPAT) {
+        lds += sizeof(uint32_t) * 624 * 2;
+        if (sizeof(uint32_t) * h->n <= 48 * 1024) {
+            p.vlist_in_lds = 1;
+            lds += sizeof(uint32_t) * h->n;
+        }
+    }
+    lds = (lds + 15) & ~(size_t)15;
+    if (lds > 160 * 1024) return fail(h, BISBM_ERR_UNSUPPORTED, "chain state needs %zu B of LDS (> 160 KiB)", lds);
+
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    HIPCHK(h, launch_sweep(p, h->rng_mode, lds, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->last_kernel_ms = ms;
+
+    std::vector<ChainScalars> sc(h->n_chains);
+    HIPCHK(h, hipMemcpy(sc.data(), h->d_scalars, sizeof(ChainScalars) * h->n_chains, hipMemcpyDeviceToHost));
+    uint64_t updates = 0;
+    for (uint32_t c = 0; c < h->n_chains; ++c) {
+        if (acc_rate_out) acc_rate_out[c] = sc[c].last_rate;
+        updates += sc[c].last_sweeps * h->n;
+    }
+    h->last_updates = updates;
+    return BISBM_OK;
+}
+
+int bisbm_get_memberships(bisbm_handle h, uint32_t chain, uint32_t* labels_out) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!labels_out || chain >= h->n_chains) return fail(h, BISBM_ERR_INVALID_ARG, "bad chain or NULL output");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, launch_labels_widen(h->d_labels + (size_t)chain * h->label_stride, h->d_stage_u32, (uint32_t)h->n, h->stream));
+    HIPCHK(h, hipMemcpyAsync(labels_out, h->d_stage_u32, sizeof(uint32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BISBM_OK;
+}
+
+int bisbm_get_block_state(bisbm_handle h, uint32_t chain, int32_t* m, int32_t* m_r, int32_t* n_r, uint32_t* eta) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    if (chain >= h->n_chains) return fail(h, BISBM_ERR_INVALID_ARG, "chain out of range");
+    if (!h->state_ready) return fail(h, BISBM_ERR_STATE, "block state not built yet");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t K = h->K, D = (size_t)h->maxdeg + 1;
+    if (m) {
+        std::vector<int32_t> quad((size_t)h->ka * h->kb);
+        HIPCHK(h, hipMemcpy(quad.data(), h->d_m + (size_t)chain * h->ka * h->kb, sizeof(int32_t) * quad.size(), hipMemcpyDeviceToHost));
+        std::memset(m, 0, sizeof(int32_t) * K * K);
+        for (uint32_t a = 0; a < h->ka; ++a)
+            for (uint32_t b = 0; b < h->kb; ++b) {
+                m[a * K + (h->ka + b)] = quad[(size_t)a * h->kb + b];
+                m[(h->ka + b) * K + a] = quad[(size_t)a * h->kb + b];
+            }
+    }
+    if (m_r) HIPCHK(h, hipMemcpy(m_r, h->d_m_r + (size_t)chain * K, sizeof(int32_t) * K, hipMemcpyDeviceToHost));
+    if (n_r) HIPCHK(h, hipMemcpy(n_r, h->d_n_r + (size_t)chain * K, sizeof(int32_t) * K, hipMemcpyDeviceToHost));
+    if (eta) HIPCHK(h, hipMemcpy(eta, h->d_eta + (size_t)chain * K * D, sizeof(uint32_t) * K * D, hipMemcpyDeviceToHost));
+    return BISBM_OK;
+}
+
+int bisbm_get_cum_dS(bisbm_handle h, double* out) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!out) return fail(h, BISBM_ERR_INVALID_ARG, "out is NULL");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<ChainScalars> sc(h->n_chains);
+    HIPCHK(h, hipMemcpy(sc.data(), h->d_scalars, sizeof(ChainScalars) * h->n_chains, hipMemcpyDeviceToHost));
+    for (uint32_t c = 0; c < h->n_chains; ++c) out[c] = sc[c].cum_dS;
+    return BISBM_OK;
+}
+
+int bisbm_get_last_counts(bisbm_handle h, uint64_t* accepted, uint64_t* sweeps) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<ChainScalars> sc(h->n_chains);
+    HIPCHK(h, hipMemcpy(sc.data(), h->d_scalars, sizeof(ChainScalars) * h->n_chains, hipMemcpyDeviceToHost));
+    for (uint32_t c = 0; c < h->n_chains; ++c) {
+        if (accepted) accepted[c] = sc[c].last_accepted;
+        if (sweeps) sweeps[c] = sc[c].last_sweeps;
+    }
+    return BISBM_OK;
+}
+
+int bisbm_entropy(bisbm_handle h, double* out) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!out) return fail(h, BISBM_ERR_INVALID_ARG, "out is NULL");
+    if (!h->state_ready) return fail(h, BISBM_ERR_STATE, "block state not built yet");
+    HIPCHK(h, hipSetDevice(h->device));
+    EntropyParams ep{};
+    ep.ka = h->ka;
+    ep.kb = h->kb;
+    ep.maxdeg = h->maxdeg;
+    ep.n_chains = h->n_chains;
+    ep.m = h->d_m;
+    ep.m_r = h->d_m_r;
+    ep.n_r = h->d_n_r;
+    ep.eta = h->d_eta;
+    ep.lgamma_tab = h->d_lgamma;
+    ep.lgamma_size = h->tab->lg.size();
+    ep.q_tab = h->d_q;
+    ep.q_stride = h->q_stride;
+    ep.out = h->d_tmp_f64;
+    HIPCHK(h, launch_entropy(ep, h->stream));
+    std::vector<double> part(h->n_chains);
+    HIPCHK(h, hipMemcpyAsync(part.data(), h->d_tmp_f64, sizeof(double) * h->n_chains, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const HostTables& t = *h->tab;
+    for (uint32_t c = 0; c < h->n_chains; ++c) {  // blockmodel.cc:753-787, statement order kept
+        double ent = h->ent_deg;
+        ent += part[c];
+        ent += h->ent_multi;
+        ent += h_lbinom_fast(t, (uint64_t)h->ka * h->kb + h->num_edges - 1, h->num_edges);
+        ent += h_lbinom_fast(t, h->na - 1, h->ka - 1);
+        ent += h_lbinom_fast(t, h->nb - 1, h->kb - 1);
+        ent += (h->na * h->nb == 0) ? 0. : std::log((double)(h->na * h->nb));  // safelog, without the na*nb table (F5)
+        ent += h_lgamma_fast(t, h->na + 1);
+        ent += h_lgamma_fast(t, h->nb + 1);
+        out[c] = ent;
+    }
+    return BISBM_OK;
+}
+
+int bisbm_marginals_reset(bisbm_handle h) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t cnt = (size_t)h->n * std::max(h->ka, h->kb);
+    if (!h->d_counts) HIPCHK(h, dalloc(&h->d_counts, cnt));
+    HIPCHK(h, hipMemsetAsync(h->d_counts, 0, sizeof(uint32_t) * cnt, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BISBM_OK;
+}
+
+int bisbm_marginals_accumulate(bisbm_handle h, uint32_t* device_counts) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!device_counts) {
+        if (!h->d_counts) {
+            int rc = bisbm_marginals_reset(h);
+            if (rc) return rc;
+        }
+        device_counts = h->d_counts;
+    }
+    MarginalParams mp{};
+    mp.n = (uint32_t)h->n;
+    mp.na = (uint32_t)h->na;
+    mp.ka = h->ka;
+    mp.kmax = std::max(h->ka, h->kb);
+    mp.n_chains = h->n_chains;
+    mp.labels = h->d_labels;
+    mp.label_stride = h->label_stride;
+    mp.counts = device_counts;
+    HIPCHK(h, launch_marginals(mp, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BISBM_OK;
+}
+
+int bisbm_marginals_get(bisbm_handle h, uint32_t* counts_out) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!counts_out) return fail(h, BISBM_ERR_INVALID_ARG, "counts_out is NULL");
+    if (!h->d_counts) return fail(h, BISBM_ERR_STATE, "no internal marginal buffer yet");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(counts_out, h->d_counts, sizeof(uint32_t) * (size_t)h->n * std::max(h->ka, h->kb), hipMemcpyDeviceToHost));
+    return BISBM_OK;
+}
+
+int bisbm_get_ka_kb(bisbm_handle h, uint32_t* ka, uint32_t* kb) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    if (ka) *ka = h->ka;
+    if (kb) *kb = h->kb;
+    return BISBM_OK;
+}
+
+int bisbm_get_sizes(bisbm_handle h, uint64_t* n, uint64_t* num_edges, uint32_t* max_degree, uint32_t* n_chains) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    if (n) *n = h->n;
+    if (num_edges) *num_edges = h->num_edges;
+    if (max_degree) *max_degree = h->maxdeg;
+    if (n_chains) *n_chains = h->n_chains;
+    return BISBM_OK;
+}
+
+int bisbm_last_sweep_timing(bisbm_handle h, double* kernel_ms, uint64_t* node_updates) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    if (kernel_ms) *kernel_ms = h->last_kernel_ms;
+    if (node_updates) *node_updates = h->last_updates;
+    return BISBM_OK;
+}
+
+int bisbm_debug_log_q(bisbm_handle h, const int32_t* n, const int32_t* k, size_t count, double* out) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!n || !k || !out) return fail(h, BISBM_ERR_INVALID_ARG, "NULL argument");
+    if (count == 0) return BISBM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    int32_t *dn = nullptr, *dk = nullptr;
+    double* dout = nullptr;
+    HIPCHK(h, dalloc(&dn, count));
+    HIPCHK(h, dalloc(&dk, count));
+    HIPCHK(h, dalloc(&dout, count));
+    HIPCHK(h, hipMemcpy(dn, n, sizeof(int32_t) * count, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(dk, k, sizeof(int32_t) * count, hipMemcpyHostToDevice));
+    Tables tab{h->d_lgamma, h->tab->lg.size(), h->d_q, h->q_stride};
+    HIPCHK(h, launch_log_q_probe(tab, dn, dk, count, dout, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, dout, sizeof(double) * count, hipMemcpyDeviceToHost));
+    (void)hipFree(dn);
+    (void)hipFree(dk);
+    (void)hipFree(dout);
+    return BISBM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,148 @@
+/*
+ * bisbm.h -- C ABI of the MI355X-native Metropolis-Hastings sweep engine for the degree-corrected
+ * bipartite SBM (libbisbm_hip.so).
+ *
+ * The reference (junipertcy/bipartiteSBM-MCMC) has no FFI; its CLI (src/mcmc_main.cc) drives the
+ * hot path through two C++ classes.  Every entry point below stands behind one of those member
+ * functions, cited as <file>:<line> relative to /root/reference/src.  Plain pointers and sizes only:
+ * no C++ types, no torch types, no exceptions across the boundary.  Host buffers are caller-owned;
+ * device memory is library-owned.  One host thread per handle.
+ *
+ * All functions return BISBM_OK (0) or a bisbm_status error code; bisbm_last_error() gives the text.
+ * There is no CPU fallback: without a HIP device bisbm_create fails with BISBM_ERR_NO_DEVICE.
+ */
+#ifndef BISBM_H
+#define BISBM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BISBM_ABI_VERSION 1
+
+typedef struct bisbm_engine *bisbm_handle;
+
+typedef enum bisbm_status {
+    BISBM_OK = 0,
+    BISBM_ERR_INVALID_ARG = 1,   /* null pointer, size mismatch, label out of range ... */
+    BISBM_ERR_NOT_BIPARTITE = 2, /* an edge joins two nodes of one type, or an id >= n */
+    BISBM_ERR_UNSUPPORTED = 3,   /* K > 256, more than 2^32-1 adjacency entries ... */
+    BISBM_ERR_NO_DEVICE = 4,     /* no HIP device / bad ordinal: the engine has no CPU path */
+    BISBM_ERR_HIP = 5,           /* a HIP runtime call failed */
+    BISBM_ERR_STATE = 6          /* call order (e.g. anneal before init/shuffle) */
+} bisbm_status;
+
+/* Random-number definition of the chain.
+ * BISBM_RNG_PHILOX         production: Philox4x32-10 counters keyed by (seed, global chain id),
+ *                          Feistel visit order per sweep, integer inverse-CDF proposal draw,
+ *                          butterfly FP64 sums (DESIGN.md "Philox-mode definition").
+ * BISBM_RNG_MT19937_COMPAT the reference's own draw sequence: std::mt19937 `engine`
+ *                          (mcmc_main.cc:242) + the hidden `gen` (blockmodel.hh:17-18),
+ *                          libstdc++-11 shuffle / generate_canonical / discrete_distribution,
+ *                          serial FP64 sums in source order.  Chain c uses engine seed `seed + c`
+ *                          and gen seed `gen_seed + c` (c = global chain id).
+ */
+typedef enum bisbm_rng { BISBM_RNG_PHILOX = 0, BISBM_RNG_MT19937_COMPAT = 1 } bisbm_rng;
+
+/* metropolis_hasting.cc:10-37 */
+typedef enum bisbm_schedule {
+    BISBM_SCHED_EXPONENTIAL = 0,
+    BISBM_SCHED_LINEAR = 1,
+    BISBM_SCHED_LOGARITHMIC = 2,
+    BISBM_SCHED_CONSTANT = 3,
+    BISBM_SCHED_ABRUPT_COOL = 4
+} bisbm_schedule;
+
+#define BISBM_ALL_CHAINS (-1)
+
+/* Replaces blockmodel_t::blockmodel_t (blockmodel.hh:22-23, blockmodel.cc:15-75; call sites
+ * mcmc_main.cc:352,420,453).  The graph is CSR of the reference's adj_list_t: row v holds the
+ * neighbours of v in edge-file order, duplicates kept (graph_utilities.cc:36-49).  Nodes
+ * [0,na) are type a, [na,na+nb) type b (mcmc_main.cc:121-130).  Blocks [0,ka) are type a,
+ * [ka,ka+kb) type b.  `n_chains` independent chains are created on HIP device `device`; chain i
+ * of this handle has global id first_chain_id + i (the id keys its random stream, so results do
+ * not depend on how chains are sharded over GPUs).  Builds the lgamma / log_q tables
+ * (support/cache.cc:64-91, support/int_part.cc:34-51) on the host and uploads them. */
+int bisbm_create(bisbm_handle *out, uint64_t n, uint64_t na, uint64_t nb, const uint64_t *rowptr,
+                 const uint32_t *col, uint32_t ka, uint32_t kb, double epsilon, uint32_t n_chains,
+                 uint32_t first_chain_id, int device, int rng_mode, uint64_t seed,
+                 uint64_t gen_seed);
+
+int bisbm_destroy(bisbm_handle h);
+
+/* Initial partition: the `memberships` constructor argument (blockmodel.cc:23), n labels in
+ * [0, ka+kb).  chain = BISBM_ALL_CHAINS copies the vector to every chain. */
+int bisbm_set_memberships(bisbm_handle h, int64_t chain, const uint32_t *labels);
+
+/* blockmodel_t::init_bisbm (blockmodel.cc:682-688): rebuild n_r, m, m_r, eta from the labels. */
+int bisbm_init(bisbm_handle h);
+
+/* blockmodel_t::shuffle_bisbm (blockmodel.cc:672-680): shuffle the type-a labels, then the
+ * type-b labels (block sizes preserved), then rebuild the block state. */
+int bisbm_shuffle(bisbm_handle h);
+
+/* metropolis_hasting::anneal (metropolis_hasting.hh:48-53, metropolis_hasting.cc:64-101) for
+ * every chain: duration_steps / n sweeps of n node updates (step :42-62, transition_ratio
+ * :103-192, single_vertex_change blockmodel.cc:613-637, apply_mcmc_moves blockmodel.cc:461-503),
+ * early stop per chain when the count of T<1 steps since the last new minimum reaches steps_await.
+ * kwargs are the two float cooling parameters (mcmc_main.cc:49).  acc_rate_out[n_chains] receives
+ * anneal's return value per chain (may be NULL). */
+int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t duration_steps,
+                 uint64_t steps_await, double *acc_rate_out);
+
+/* blockmodel_t::get_memberships (blockmodel.cc:87) for one chain: n labels. */
+int bisbm_get_memberships(bisbm_handle h, uint32_t chain, uint32_t *labels_out);
+
+/* get_m / get_m_r / get_n_r / get_eta_rk_ (blockmodel.cc:93-99) for one chain.
+ * m is the reference's full symmetric K*K matrix (row-major), eta is K*(max_degree+1).
+ * Any output pointer may be NULL. */
+int bisbm_get_block_state(bisbm_handle h, uint32_t chain, int32_t *m, int32_t *m_r, int32_t *n_r,
+                          uint32_t *eta);
+
+/* blockmodel_t::get_entropy (blockmodel.cc:91): running sum of accepted dS, per chain. */
+int bisbm_get_cum_dS(bisbm_handle h, double *out);
+
+/* blockmodel_t::entropy (blockmodel.cc:753-787): full description length, per chain.  The
+ * reference's log(na*nb) table growth (cache.hh:47-57) that aborts on large graphs
+ * is replaced by a direct log(). */
+int bisbm_entropy(bisbm_handle h, double *out);
+
+/* Bookkeeping of the last bisbm_anneal per chain: accepted steps and sweeps executed
+ * (metropolis_hasting.cc:72,97,100).  Either pointer may be NULL. */
+int bisbm_get_last_counts(bisbm_handle h, uint64_t *accepted, uint64_t *sweeps);
+
+/* Marginal accumulation the README describes for "marginalize" (README.md:49-53; the code at
+ * mcmc_main.cc:61-65 parses -b/-f and never uses them): add one sample of every chain's labels
+ * to counts[n][kmax], kmax = max(ka,kb), column = block index within the node's type.
+ * device_counts is a DEVICE pointer to n*kmax uint32 owned by the caller (e.g. a torch tensor
+ * that RCCL then reduces across ranks); NULL uses an internal buffer read by bisbm_marginals_get. */
+int bisbm_marginals_accumulate(bisbm_handle h, uint32_t *device_counts);
+int bisbm_marginals_reset(bisbm_handle h);
+int bisbm_marginals_get(bisbm_handle h, uint32_t *counts_out /* n*kmax, host */);
+
+/* Shape queries (get_KA/get_KB blockmodel.cc:103-105, get_num_edges :81). */
+int bisbm_get_ka_kb(bisbm_handle h, uint32_t *ka, uint32_t *kb);
+int bisbm_get_sizes(bisbm_handle h, uint64_t *n, uint64_t *num_edges, uint32_t *max_degree,
+                    uint32_t *n_chains);
+
+/* Run kernels on a caller-provided hipStream_t (NULL = the handle's own stream). */
+int bisbm_set_stream(bisbm_handle h, void *hip_stream);
+
+/* Device time of the sweep kernel of the last bisbm_anneal, measured with HIP events on the
+ * launch stream, and the number of node updates it executed (all chains). */
+int bisbm_last_sweep_timing(bisbm_handle h, double *kernel_ms, uint64_t *node_updates);
+
+/* Device numerics probe (tests): evaluates log_q(n[i], k[i]) on the device (int_part.hh:27-37). */
+int bisbm_debug_log_q(bisbm_handle h, const int32_t *n, const int32_t *k, size_t count,
+                      double *out);
+
+const char *bisbm_last_error(bisbm_handle h); /* h may be NULL: error of the last failed create */
+int bisbm_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BISBM_H */

@@ -1,0 +1,94 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads without a GPU and exports every
+symbol include/*.h declares; no compute is called here."""
+import ctypes as C
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B = importlib.import_module("bipartitesbm-mcmc_amd")
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(bisbm_[a-z_0-9A-Z]+)\s*\(", text))
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not os.path.exists(B.LIB_PATH):
+        B.build()
+    return B.lib()
+
+
+def test_every_declared_symbol_is_exported_and_bound(built):
+    declared = _declared("bisbm.h") | _declared("bisbm_io.h")
+    assert declared, "header parse failed"
+    raw = C.CDLL(B.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), "libbisbm_hip.so does not export %s" % name
+    assert declared == set(B.ABI), (declared ^ set(B.ABI))
+    assert built.bisbm_abi_version() == 1
+
+
+def test_header_cites_the_reference_interface():
+    text = open(os.path.join(ROOT, "include", "bisbm.h")).read()
+    for cite in ("blockmodel.hh:22-23", "metropolis_hasting.hh:48-53", "blockmodel.cc:672-680",
+                 "blockmodel.cc:682-688", "blockmodel.cc:753-787", "metropolis_hasting.cc:64-101"):
+        assert cite in text
+
+
+def test_no_device_fails_loudly(built):
+    """Without a HIP device create must fail with NO_DEVICE (never fall back to a CPU path).  On a
+    GPU box the same call succeeds, so the check is only made when no device is visible."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    rowptr = np.array([0, 1, 2], dtype=np.uint64)
+    col = np.array([1, 0], dtype=np.uint32)
+    with pytest.raises(B.BisbmError) as e:
+        B.BlockModel([0, 1], [0, 1], 2, 1, 1, 1.0, (rowptr, col))
+    assert e.value.code == B.BISBM_ERR_NO_DEVICE
+    # argument validation happens before the device is touched
+    with pytest.raises(B.BisbmError) as e:
+        B.BlockModel([0, 0], [0, 0], 2, 1, 1, 1.0, (rowptr, col))
+    assert e.value.code in (B.BISBM_ERR_NOT_BIPARTITE, B.BISBM_ERR_INVALID_ARG)
+
+
+def test_product_does_not_touch_the_oracle():
+    """The product package must not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "bipartitesbm-mcmc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower().replace("no cpu fallback", ""), f
+                assert "orc_" not in text, f
+
+
+def test_host_io_matches_oracle(built, tmp_path):
+    import oracle_lib as O
+    p = tmp_path / "q.el"
+    p.write_text("0\t5\n1 6\n\n2   7\r\nabc def\n3\n4 8 junk\n  1\t9  \n")
+    a, b = B.load_edge_list(str(p))
+    oa, ob = O.load_edge_list(str(p))
+    assert (a == oa).all() and (b == ob).all()
+    for name, n in (("southernWomen.edgelist", 32), ("bisbm-n_1000-ka_4-kb_6.edgelist", 1000)):
+        path = os.path.join(O.GOLDEN, name)
+        a, b = B.load_edge_list(path)
+        oa, ob = O.load_edge_list(path)
+        assert (a == oa).all() and (b == ob).all()
+        r1, c1 = B.edge_to_adj((a, b), n)
+        r2, c2 = O.edge_to_csr(oa, ob, n)
+        assert (r1 == r2).all() and (c1 == c2).all()
+    mb = B.load_memberships(os.path.join(O.GOLDEN, "n_1000_membership.txt"))
+    assert (mb == O.load_memberships(os.path.join(O.GOLDEN, "n_1000_membership.txt"))).all()
+    assert B.output_vec([3, 0, 12, 7], stream=open(os.devnull, "w")) == O.format_vec([3, 0, 12, 7]) == "3 0 12 7 \n"
+    with pytest.raises(FileNotFoundError):
+        B.load_edge_list(str(tmp_path / "missing"))
+    with pytest.raises(ValueError):
+        B.edge_to_adj((np.array([0]), np.array([5])), 3)

@@ -1,0 +1,108 @@
+"""World-size-2 gloo tests (CPU) of the chain sharding and pooling layer
+(bipartitesbm-mcmc_amd/distributed.py).  Per-rank chain results come from the oracle in Philox mode,
+whose streams are keyed by the GLOBAL chain id -- the same property the GPU path relies on -- so the
+pooled result must be independent of world_size."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as O
+
+B = importlib.import_module("bipartitesbm-mcmc_amd")
+D = B.distributed
+
+TOTAL_CHAINS = 7  # odd on purpose: uneven shards
+SWEEPS = 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run_chain(gid):
+    rowptr, col, na, nb = O.load_graph("southernWomen")
+    m = O.OracleModel(rowptr, col, na, nb, 5, 5, 0.001, O.contiguous_labels(na, nb, 5, 5))
+    m.seed_philox(31337, gid)
+    m.shuffle_bisbm()
+    rate = m.anneal("constant", [1.0], SWEEPS * 32, 1 << 60)
+    return m.memberships(), rate, m.get_entropy()
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shard = D.ChainShard(TOTAL_CHAINS)
+        assert (shard.rank, shard.world_size) == (rank, world)
+        labs, rates, cums = [], [], []
+        for c in range(shard.n_local):
+            l, r, e = _run_chain(shard.first_chain_id + c)
+            labs.append(l)
+            rates.append(r)
+            cums.append(e)
+        local = torch.tensor(np.stack([rates, cums], axis=1), dtype=torch.float64).reshape(-1, 2)
+        allv = shard.all_gather_chain_values(local)
+        counts = torch.from_numpy(D.numpy_marginals(np.array(labs).reshape(-1, 32), 18, 5, 5))
+        pooled = shard.pooled_marginals(counts)
+        mapl = shard.map_labels(counts, 18, 5)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "allv.npy"), allv.numpy())
+            np.save(os.path.join(out_dir, "pooled.npy"), pooled.numpy())
+            np.save(os.path.join(out_dir, "map.npy"), mapl.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_chains_partition():
+    for total in (1, 7, 8, 1024, 8192):
+        for world in (1, 2, 3, 8):
+            spans = [D.shard_chains(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0
+            assert sum(n for _, n in spans) == total
+            for (f0, n0), (f1, _) in zip(spans, spans[1:]):
+                assert f0 + n0 == f1
+            assert max(n for _, n in spans) - min(n for _, n in spans) <= 1
+    with pytest.raises(ValueError):
+        D.shard_chains(4, 2, 2)
+
+
+def test_world2_gloo_pooling_equals_single_process(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    allv = np.load(tmp_path / "allv.npy")
+    pooled = np.load(tmp_path / "pooled.npy")
+    mapl = np.load(tmp_path / "map.npy")
+    # single-process truth
+    labs, vals = [], []
+    for gid in range(TOTAL_CHAINS):
+        l, r, e = _run_chain(gid)
+        labs.append(l)
+        vals.append((r, e))
+    assert allv.shape == (TOTAL_CHAINS, 2)
+    assert (allv == np.array(vals)).all()  # global chain order, bit-exact
+    want = D.numpy_marginals(np.array(labs), 18, 5, 5)
+    assert (pooled == want).all()
+    assert pooled.sum() == TOTAL_CHAINS * 32
+    base = np.where(np.arange(32) >= 18, 5, 0)
+    assert (mapl == want.argmax(axis=1) + base).all()
+
+
+def test_single_process_paths():
+    shard = D.ChainShard(5, rank=0, world_size=1)
+    x = torch.arange(10, dtype=torch.float64).reshape(5, 2)
+    assert torch.equal(shard.all_gather_chain_values(x), x)
+    counts = torch.tensor([[1, 3, 3], [2, 0, 1], [0, 0, 4]], dtype=torch.int32)
+    assert torch.equal(shard.pooled_marginals(counts), counts)
+    assert shard.map_labels(counts, 2, 3).tolist() == [1, 0, 5]

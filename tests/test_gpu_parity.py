@@ -1,0 +1,279 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (ctypes), against
+  * the golden reference outputs recorded by the survey (mt19937-compat mode, bit-exact),
+  * the oracle restatement on the same seeded inputs (both RNG modes, integers bit-exact),
+  * size-independent properties at BASELINE.json's full size."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+B = importlib.import_module("bipartitesbm-mcmc_amd")
+SYN = importlib.import_module("bipartitesbm-mcmc_amd.synthetic")
+BIG = 1 << 60
+
+
+def gpu_model(rowptr, col, na, nb, ka, kb, eps, labels, **kw):
+    return B.BlockModel(labels, SYN.types_vector(na, nb), ka + kb, ka, kb, eps, (rowptr, col), **kw)
+
+
+def assert_state_equal(g, o, chain=0):
+    assert (g.get_memberships(chain) == o.memberships()).all()
+    assert (g.get_m(chain) == o.m()).all()
+    assert (g.get_m_r(chain) == o.m_r()).all()
+    assert (g.get_n_r(chain) == o.n_r()).all()
+    assert (g.get_eta_rk_(chain) == o.eta()).all()
+
+
+# ------------------------------------------------------------------ golden: reference outputs
+def _golden_run(golden, key):
+    g = golden["compat_rng"][key]
+    rowptr, col, na, nb = O.load_graph(g["graph"])
+    labels = O.contiguous_labels(na, nb, g["ka"], g["kb"])
+    m = gpu_model(rowptr, col, na, nb, g["ka"], g["kb"], g["epsilon"], labels, rng="compat", seed=42, gen_seed=43)
+    m.shuffle_bisbm()
+    return g, m
+
+
+@pytest.mark.parametrize("key", ["sample_southernWomen", "sample_n_1000"])
+def test_golden_first_sweep(golden, key):
+    g, m = _golden_run(golden, key)
+    assert m.entropy()[0] == pytest.approx(g["S0"], rel=1e-13)
+    rate = B.MetropolisHasting().anneal(m, g["schedule"], g["kwargs"], g["duration"], BIG)
+    assert rate == g["rate"]
+    assert m.get_entropy()[0] == pytest.approx(g["sum_dS"], rel=1e-12)
+
+
+def test_golden_scenario1_config1(golden):
+    """BASELINE config 1: southernWomen, Ka=Kb=5, exponential(10, 0.1), early stop; labels bit-exact."""
+    g, m = _golden_run(golden, "scenario1_config1")
+    rate = B.MetropolisHasting().anneal(m, B.exponential_schedule, g["kwargs"], g["duration"], g["steps_await"])
+    assert rate == g["rate"]
+    acc, sw = m.last_counts()
+    assert acc[0] == g["accepted"] and sw[0] == g["sweeps"]
+    assert list(m.get_memberships()) == g["labels"]
+    assert m.get_entropy()[0] == pytest.approx(g["sum_dS"], rel=1e-12)
+    assert m.entropy()[0] == pytest.approx(g["entropy_approx"], abs=1e-3)
+
+
+def test_golden_scenario2(golden):
+    g, m = _golden_run(golden, "scenario2_n1000_constant")
+    rate = B.MetropolisHasting().anneal(m, g["schedule"], g["kwargs"], g["duration"], BIG)
+    assert rate == g["rate"]
+    assert m.get_entropy()[0] == pytest.approx(g["sum_dS"], rel=1e-12)
+
+
+def test_golden_scenario3(golden):
+    g, m = _golden_run(golden, "scenario3_n1000_abrupt")
+    rate = B.MetropolisHasting().anneal(m, g["schedule"], g["kwargs"], g["duration"], g["steps_await"])
+    assert rate == g["rate"]
+    assert m.get_entropy()[0] == pytest.approx(g["sum_dS"], rel=1e-12)
+
+
+def test_golden_rng_free_state(golden):
+    g = golden["rng_free"]["n_1000"]
+    rowptr, col, na, nb = O.load_graph("n_1000")
+    labels = O.load_memberships(os.path.join(O.GOLDEN, g["membership"]))
+    m = gpu_model(rowptr, col, na, nb, 4, 6, 1.0, labels)
+    m.init_bisbm()
+    assert list(m.get_m_r()) == g["m_r"]
+    assert list(m.get_m()[0]) == g["m_row0"]
+    assert m.entropy()[0] == pytest.approx(g["entropy"], rel=1e-13)
+    g = golden["rng_free"]["southernWomen"]
+    rowptr, col, na, nb = O.load_graph("southernWomen")
+    m = gpu_model(rowptr, col, na, nb, 5, 5, 0.001, O.labels_from_sizes(g["block_sizes"]))
+    m.init_bisbm()
+    assert list(m.get_m_r()) == g["m_r"]
+    assert m.entropy()[0] == pytest.approx(g["entropy"], rel=1e-13)
+
+
+# ------------------------------------------------------------------ oracle, same seeded inputs
+def _random_graph(seed, na, nb, ne, ka, kb, hubs=0, isolated=0):
+    a, b = SYN.planted_edges(na - isolated, nb - isolated, ne, max(ka, 1), max(kb, 1), seed=seed)
+    b = b - (na - isolated) + na  # keep b ids in [na, na+nb-isolated)
+    if hubs:  # a few nodes with degree > 64 (more than one wave of neighbours)
+        rng = np.random.default_rng(seed + 100)
+        ha = rng.integers(0, hubs, 150 * hubs).astype(np.uint64)
+        hb = (na + rng.integers(0, nb - isolated, 150 * hubs)).astype(np.uint64)
+        a, b = np.concatenate([a, ha]), np.concatenate([b, hb])
+    rowptr, col = O.edge_to_csr(a, b, na + nb)
+    return rowptr, col
+
+
+CASES = [
+    # name, na, nb, edges, ka, kb, eps, hubs, isolated
+    ("tiny", 12, 9, 40, 3, 2, 0.5, 0, 0),
+    ("ka1", 40, 30, 300, 1, 4, 1.0, 0, 0),
+    ("hubs_isolated", 300, 200, 3000, 5, 7, 1.0, 3, 4),
+    ("wideK", 400, 300, 6000, 70, 3, 2.0, 0, 0),       # K_type > 64: chunked lane loops
+    ("big_m_r", 150, 150, 60000, 2, 3, 1.0, 0, 0),     # m_r > 10^4: log_q_approx on the device
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("mode", ["compat", "philox"])
+def test_matches_oracle(case, mode):
+    name, na, nb, ne, ka, kb, eps, hubs, iso = case
+    rowptr, col = _random_graph(11, na, nb, ne, ka, kb, hubs, iso)
+    labels = O.contiguous_labels(na, nb, ka, kb)
+    n = na + nb
+    o = O.OracleModel(rowptr, col, na, nb, ka, kb, eps, labels)
+    if mode == "compat":
+        o.seed_compat(5, 6)
+        g = gpu_model(rowptr, col, na, nb, ka, kb, eps, labels, rng="compat", seed=5, gen_seed=6)
+    else:
+        o.seed_philox(777, 3)
+        g = gpu_model(rowptr, col, na, nb, ka, kb, eps, labels, rng="philox", seed=777, first_chain_id=3)
+    o.shuffle_bisbm()
+    g.shuffle_bisbm()
+    assert_state_equal(g, o)
+    assert g.entropy()[0] == pytest.approx(o.entropy(), rel=1e-12)
+    mh = B.MetropolisHasting()
+    for sched, kw, dur, await_ in [("constant", [1.0], 6 * n, BIG), ("linear", [2.0, 1e-4], 3 * n, BIG),
+                                   ("abrupt_cool", [float(n)], 4 * n, BIG), ("exponential", [3.0, 0.999], 3 * n, 2 * n)]:
+        ro = o.anneal(sched, kw, dur, await_)
+        rg = mh.anneal(g, sched, kw, dur, await_)
+        assert rg == ro, (sched, rg, ro)
+        assert_state_equal(g, o)
+        acc, sw = g.last_counts()
+        assert acc[0] == o.last_accepted and sw[0] == o.last_sweeps
+        assert g.get_entropy()[0] == pytest.approx(o.get_entropy(), rel=1e-9, abs=1e-9)
+    assert g.entropy()[0] == pytest.approx(o.entropy(), rel=1e-9)
+
+
+def test_config2_256_chains_philox():
+    """BASELINE config 2: n_1000, Ka=4, Kb=6, 256 independent chains, constant T=1."""
+    rowptr, col, na, nb = O.load_graph("n_1000")
+    labels = O.contiguous_labels(na, nb, 4, 6)
+    chains, sweeps, first = 256, 4, 1000
+    g = gpu_model(rowptr, col, na, nb, 4, 6, 1.0, labels, n_chains=chains, rng="philox", seed=2024, first_chain_id=first)
+    g.shuffle_bisbm()
+    rates = B.MetropolisHasting().anneal(g, B.constant_schedule, [1.0], sweeps * 1000, BIG)
+    cum = g.get_entropy()
+    ent = g.entropy()
+    labs = []
+    for c in range(chains):
+        o = O.OracleModel(rowptr, col, na, nb, 4, 6, 1.0, labels)
+        o.seed_philox(2024, first + c)
+        o.shuffle_bisbm()
+        ro = o.anneal("constant", [1.0], sweeps * 1000, BIG)
+        assert rates[c] == ro
+        if c % 16 == 0:
+            assert_state_equal(g, o, c)
+            assert ent[c] == pytest.approx(o.entropy(), rel=1e-9)
+        else:
+            assert (g.get_memberships(c) == o.memberships()).all()
+        assert cum[c] == pytest.approx(o.get_entropy(), rel=1e-9)
+        labs.append(o.memberships())
+    # chains differ from each other
+    assert len({tuple(l) for l in labs}) == chains
+    # marginal histogram over the 256 chains
+    g.marginals_reset()
+    g.marginals_accumulate()
+    want = B.distributed.numpy_marginals(np.array(labs), na, 4, 6)
+    assert (g.marginals_get().astype(np.int64) == want).all()
+
+
+def test_anneal_splits_compose_on_device():
+    rowptr, col, na, nb = O.load_graph("n_1000")
+    labels = O.contiguous_labels(na, nb, 4, 6)
+    mh = B.MetropolisHasting()
+    for mode, kw in (("compat", dict(seed=9, gen_seed=10)), ("philox", dict(seed=9))):
+        a = gpu_model(rowptr, col, na, nb, 4, 6, 1.0, labels, rng=mode, **kw)
+        b = gpu_model(rowptr, col, na, nb, 4, 6, 1.0, labels, rng=mode, **kw)
+        a.shuffle_bisbm()
+        b.shuffle_bisbm()
+        mh.anneal(a, "constant", [1.0], 5000, BIG)
+        for _ in range(5):
+            mh.anneal(b, "constant", [1.0], 1000, BIG)
+        assert (a.get_memberships() == b.get_memberships()).all()
+        assert a.get_entropy()[0] == b.get_entropy()[0]
+
+
+def test_device_log_q_matches_oracle():
+    rowptr, col, na, nb = O.load_graph("n_1000")
+    g = gpu_model(rowptr, col, na, nb, 4, 6, 1.0, O.contiguous_labels(na, nb, 4, 6))
+    L = O.lib()
+    rng = np.random.default_rng(3)
+    n = np.concatenate([rng.integers(1, 10001, 3000), rng.integers(10001, 2_000_000, 3000),
+                        [0, -5, 7, 10000, 10001, 312500, 312500, 160000]]).astype(np.int32)
+    k = np.concatenate([rng.integers(1, 501, 3000), rng.integers(1, 100_000, 3000),
+                        [3, 3, 0, 500, 500, 15625, 20, 20]]).astype(np.int32)
+    k[:3000] = np.minimum(k[:3000], 500)
+    got = g.debug_log_q(n, k)
+    want = np.array([L.orc_log_q(int(a), int(b)) for a, b in zip(n, k)])
+    table = n < 10001
+    assert (got[table] == want[table]).all()  # host-built table: same bits
+    assert np.allclose(got[~table], want[~table], rtol=1e-12, atol=0)  # device libm vs glibc
+
+
+def test_error_paths():
+    rowptr, col, na, nb = O.load_graph("southernWomen")
+    labels = O.labels_from_sizes([4, 4, 4, 3, 3, 3, 3, 3, 3, 2])
+    with pytest.raises(B.BisbmError) as e:
+        gpu_model(rowptr, col, na + 1, nb - 1, 5, 5, 1.0, labels)  # node 18 becomes type a: a-a edges
+    assert e.value.code == B.BISBM_ERR_NOT_BIPARTITE
+    with pytest.raises(B.BisbmError) as e:
+        gpu_model(rowptr, col, na, nb, 200, 100, 1.0, labels)
+    assert e.value.code == B.BISBM_ERR_UNSUPPORTED
+    bad = labels.copy()
+    bad[0] = 7  # a type-b block for a type-a node
+    with pytest.raises(B.BisbmError) as e:
+        gpu_model(rowptr, col, na, nb, 5, 5, 1.0, bad)
+    assert e.value.code == B.BISBM_ERR_INVALID_ARG
+    m = gpu_model(rowptr, col, na, nb, 5, 5, 1.0, labels)
+    with pytest.raises(B.BisbmError) as e:
+        B.MetropolisHasting().anneal(m, "constant", [1.0], 32, BIG)  # no init_bisbm / shuffle_bisbm yet
+    assert e.value.code == B.BISBM_ERR_STATE
+    with pytest.raises(B.BisbmError) as e:
+        gpu_model(rowptr, col, na, nb, 5, 5, 1.0, labels, device=99)
+    assert e.value.code == B.BISBM_ERR_NO_DEVICE
+
+
+def test_io_round_trip(tmp_path):
+    """Host I/O of the product library against the oracle's restatement (itself checked against the
+    reference's graph_utilities.cc in the CPU suite)."""
+    p = tmp_path / "q.el"
+    p.write_text("0\t5\n1 6\n\n2   7\r\nabc def\n3\n4 8 junk\n")
+    a, b = B.load_edge_list(str(p))
+    oa, ob = O.load_edge_list(str(p))
+    assert (a == oa).all() and (b == ob).all()
+    r1, c1 = B.edge_to_adj((a, b), 9)
+    r2, c2 = O.edge_to_csr(oa, ob, 9)
+    assert (r1 == r2).all() and (c1 == c2).all()
+    assert B.output_vec([3, 0, 12], stream=open(os.devnull, "w")) == "3 0 12 \n"
+
+
+# ------------------------------------------------------------------ full size: properties
+def test_full_size_properties():
+    """BASELINE config 3 graph (N_a=N_b=5e5, E=1e7, Ka=Kb=32) with a handful of chains: one sweep keeps
+    the incremental state equal to a recount, block sizes sum to N, and sum dS equals the change of
+    the full description length."""
+    na = nb = 500_000
+    ka = kb = 32
+    a, b = SYN.planted_edges(na, nb, 10_000_000, ka, kb, seed=1)
+    rowptr, col = B.edge_to_adj((a, b), na + nb)
+    labels = SYN.contiguous_labels(na, nb, ka, kb)
+    chains = 8
+    g = gpu_model(rowptr, col, na, nb, ka, kb, 1.0, labels, n_chains=chains, rng="philox", seed=1)
+    g.shuffle_bisbm()
+    s0 = g.entropy()
+    rates = B.MetropolisHasting().anneal(g, "constant", [1.0], na + nb, BIG)
+    assert ((rates > 0.3) & (rates <= 1.0)).all()
+    s1 = g.entropy()
+    cum = g.get_entropy()
+    assert np.allclose(s1 - s0, cum, rtol=1e-9, atol=1e-6 * np.abs(cum).max())
+    before = [(g.get_m(c), g.get_m_r(c), g.get_n_r(c), g.get_eta_rk_(c)) for c in (0, chains - 1)]
+    labs = [g.get_memberships(c) for c in (0, chains - 1)]
+    g.init_bisbm()  # recount from the labels
+    for (m, m_r, n_r, eta), c, lab in zip(before, (0, chains - 1), labs):
+        assert (g.get_m(c) == m).all() and (g.get_m_r(c) == m_r).all()
+        assert (g.get_n_r(c) == n_r).all() and (g.get_eta_rk_(c) == eta).all()
+        assert n_r.sum() == na + nb and m_r.sum() == 2 * 10_000_000
+        assert (np.bincount(lab, minlength=ka + kb) == n_r).all()
+    ms, updates = g.last_sweep_timing()
+    assert updates == chains * (na + nb) and ms > 0
