@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- node-label MH updates/s of the sweep engine on BASELINE.json's headline workload.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (configs[2] of BASELINE.json, the configuration the metric is quoted on): synthetic planted
+bipartite graph N_a = N_b = 5e5, E = 1e7, Ka = Kb = 32 (graph seed 1), 1024
+independent chains PER GPU, constant T = 1, epsilon = 1, randomised start ("marginalize" regime).
+One step = one sweep = one pass of the hot path (n node updates) over every chain = one sweep-kernel
+launch.  Inputs (CSR, labels, tables) are resident in HBM before the timed region starts.
+Chains shard over GPUs with no collective in the sweep path (scaling = "weak": 1024 chains per GPU);
+the RCCL pooling of per-chain sums runs after the timed region.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: sweep_kernel, HBM-bound, measured
+with HIP events on the launch stream) and `cpu_baseline` (the oracle restatement timed on one host
+core on a bounded sample of the same workload; N = 1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md chip table: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def b_alg_per_update(n, n_edges, label_bytes=1):
+    """8 (two row offsets) + (4 + L) * mean degree (neighbour ids + labels) + 2 L."""
+    return 8.0 + (4.0 + label_bytes) * (2.0 * n_edges / n) + 2.0 * label_bytes
+
+
+def cpu_baseline(rowptr, col, na, nb, ka, kb, eps, labels, seconds_budget=20.0):
+    """The oracle (kind "port": bit-exact with the reference in compat mode, see tests) timed on ONE
+    host core: anneal() only, init excluded, constant T = 1 after a randomised start."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    n = na + nb
+    m = O.OracleModel(rowptr, col, na, nb, ka, kb, eps, labels)
+    m.seed_compat(42, 43)
+    m.shuffle_bisbm()
+    t0 = time.perf_counter()
+    m.anneal("constant", [1.0], n, 1 << 60)  # one sweep to size the sample
+    dt1 = time.perf_counter() - t0
+    extra = int(max(0, min(50, (seconds_budget - dt1) // max(dt1, 1e-9))))
+    steps, dt = n, dt1
+    if extra > 0:
+        t0 = time.perf_counter()
+        m.anneal("constant", [1.0], extra * n, 1 << 60)
+        dt += time.perf_counter() - t0
+        steps += extra * n
+    return {"value": steps / dt, "unit": "updates/s", "cores": 1, "kind": "port",
+            "sample": "oracle/bisbm_oracle.c (mt19937-compat), 1 chain, %d sweeps of the same graph, "
+                      "anneal() wall time only, %.1f s" % (steps // n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--chains", type=int, default=1024, help="chains per GPU")
+    ap.add_argument("--na", type=int, default=500_000)
+    ap.add_argument("--nb", type=int, default=500_000)
+    ap.add_argument("--edges", type=int, default=10_000_000)
+    ap.add_argument("--ka", type=int, default=32)
+    ap.add_argument("--kb", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = importlib.import_module("bipartitesbm-mcmc_amd")
+    syn = importlib.import_module("bipartitesbm-mcmc_amd.synthetic")
+    if not os.path.exists(pkg.LIB_PATH):
+        pkg.build()
+
+    na, nb, ka, kb, E = args.na, args.nb, args.ka, args.kb, args.edges
+    n = na + nb
+    a, b = syn.planted_edges(na, nb, E, ka, kb, seed=1)
+    rowptr, col = pkg.edge_to_adj((a, b), n)
+    del a, b
+    labels = syn.contiguous_labels(na, nb, ka, kb)
+    shard = pkg.ChainShard(args.chains * world, rank=rank, world_size=world)
+    model = pkg.BlockModel(labels, syn.types_vector(na, nb), ka + kb, ka, kb, 1.0, (rowptr, col),
+                           n_chains=shard.n_local, rng="philox", seed=20240229, device=local_rank,
+                           first_chain_id=shard.first_chain_id)
+    model.shuffle_bisbm()  # --randomize start
+    mh = pkg.MetropolisHasting()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        mh.anneal(model, pkg.constant_schedule, [1.0], n, 1 << 60)
+    sync()
+    t0 = time.perf_counter()
+    kernel_ms, updates = 0.0, 0
+    for _ in range(args.steps):
+        mh.anneal(model, pkg.constant_schedule, [1.0], n, 1 << 60)  # blocks until the sweep kernel is done
+        ms, upd = model.last_sweep_timing()
+        kernel_ms += ms
+        updates += upd
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        u = torch.tensor([updates], dtype=torch.int64, device="cuda")
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        total_updates = int(u.item())
+    else:
+        total_updates = updates
+
+    # pooling epilogue (outside the timed region): RCCL all_gather of the per-chain sums
+    cum = torch.from_numpy(model.get_entropy()).to("cuda").reshape(-1, 1)
+    t1 = time.perf_counter()
+    allcum = shard.all_gather_chain_values(cum)
+    torch.cuda.synchronize()
+    pool_ms = (time.perf_counter() - t1) * 1e3
+    assert allcum.shape[0] == args.chains * world and bool(torch.isfinite(allcum).all())
+
+    if rank == 0:
+        per_launch_updates = updates / max(args.steps, 1)
+        avg_kernel_s = kernel_ms / max(args.steps, 1) / 1e3
+        balg = b_alg_per_update(n, E)
+        achieved = balg * per_launch_updates / avg_kernel_s / 1e9
+        default_cfg = (na, nb, E, ka, kb, args.chains) == (500_000, 500_000, 10_000_000, 32, 32, 1024)
+        out = {
+            "metric": "node-label MH updates/s",
+            "value": total_updates / elapsed,
+            "unit": "updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "sweeps_per_s": total_updates / elapsed / n,
+            "config": {
+                "workload": ("BASELINE configs[2]: " if default_cfg else "custom: ")
+                + "planted bipartite N_a=%d N_b=%d E=%d Ka=%d Kb=%d, %d chains/GPU, constant T=1, eps=1, "
+                  "randomised start, Philox mode" % (na, nb, E, ka, kb, args.chains),
+                "chains_total": args.chains * world, "step": "one sweep (n node updates) of every chain",
+                "parallelism": "chains sharded, no collective in the sweep path",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "sweep_kernel<philox>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "alg_bytes_per_update": balg, "updates_per_launch": per_launch_updates,
+                "avg_launch_ms": avg_kernel_s * 1e3,
+            },
+            "pool_all_gather_ms": pool_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(rowptr, col, na, nb, ka, kb, 1.0, labels)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -199,11 +199,14 @@ def test_device_log_q_matches_oracle():
     g = gpu_model(rowptr, col, na, nb, 4, 6, 1.0, O.contiguous_labels(na, nb, 4, 6))
     L = O.lib()
     rng = np.random.default_rng(3)
-    n = np.concatenate([rng.integers(1, 10001, 3000), rng.integers(10001, 2_000_000, 3000),
-                        [0, -5, 7, 10000, 10001, 312500, 312500, 160000]]).astype(np.int32)
-    k = np.concatenate([rng.integers(1, 501, 3000), rng.integers(1, 100_000, 3000),
-                        [3, 3, 0, 500, 500, 15625, 20, 20]]).astype(np.int32)
-    k[:3000] = np.minimum(k[:3000], 500)
+    # table branch (n <= 10000), approximation branch (k >= n^(1/4)) at any n, and the small-k branch
+    # (lbinom through the lgamma table) for n inside this model's table (2E+2 = 30002 entries)
+    n_big = rng.integers(10001, 2_000_000, 3000)
+    k_big = np.maximum(rng.integers(1, 100_000, 3000), np.ceil(n_big ** 0.25).astype(np.int64) + 1)
+    n = np.concatenate([rng.integers(1, 10001, 3000), n_big,
+                        [0, -5, 7, 10000, 10001, 312500, 20000, 25000, 29000, 160000]]).astype(np.int32)
+    k = np.concatenate([np.minimum(rng.integers(1, 501, 3000), 500), k_big,
+                        [3, 3, 0, 500, 500, 15625, 5, 11, 2, 21]]).astype(np.int32)
     got = g.debug_log_q(n, k)
     want = np.array([L.orc_log_q(int(a), int(b)) for a, b in zip(n, k)])
     table = n < 10001
