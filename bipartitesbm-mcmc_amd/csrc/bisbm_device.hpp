@@ -27,6 +27,17 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ double bcast(double x, int src) { return __shfl(x, src, kWave); }
 __device__ __forceinline__ int bcast(int x, int src) { return __shfl(x, src, kWave); }
 
+// v_readlane with a wave-uniform lane index: the value lands in scalar registers, no LDS crossbar
+__device__ __forceinline__ int readlane(int x, uint32_t src) { return __builtin_amdgcn_readlane(x, (int)src); }
+__device__ __forceinline__ uint32_t readlane(uint32_t x, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)src);
+}
+__device__ __forceinline__ double readlane(double x, uint32_t src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), (int)src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), (int)src);
+    return __hiloint2double(hi, lo);
+}
+
 // Fixed 64-leaf xor butterfly, levels 1,2,4,8,16,32: the summation tree of Philox mode.  FP add is
 // commutative, so every lane ends with the same bits.
 __device__ __forceinline__ double butterfly_sum(double x) {
@@ -291,7 +302,7 @@ __device__ inline double get_v(double u) {  // int_part.cc:77-87
     return v;
 }
 
-__device__ __noinline__ double log_q_approx(const Tables& t, unsigned long long n, unsigned long long k) {
+__device__ inline double log_q_approx(const Tables& t, unsigned long long n, unsigned long long k) {
     const double kPi = 3.14159265358979323846;
     if ((double)k < pow((double)n, 1 / 4.))  // int_part.cc:73-75,90-91
         return lbinom_fast(t, n - 1, k - 1) - lgamma_fast(t, (long long)(k + 1));

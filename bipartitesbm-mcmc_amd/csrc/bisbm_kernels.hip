@@ -75,32 +75,39 @@ __device__ __forceinline__ double temperature(const SweepParams& p, uint64_t t) 
 
 // ------------------------------------------------------------------------------------------
 // one MH step for node v (metropolis_hasting.cc:42-62)
+//
+// The caller hands over the node's CSR row already in registers: lane j holds neighbour id nb and
+// its label lab for j < min(deg, 64) (prefetched one step ahead, see sweep_kernel); neighbours
+// beyond 64 are read here.  No workgroup barrier is used on this path: a barrier makes the compiler
+// drain every outstanding global load (vmcnt(0)), which would serialise the prefetch pipeline.  The
+// wave's LDS operations execute in issue order, so wave_fence() (a code-motion barrier only) is
+// enough between a lane's LDS write and another lane's read.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_wave_barrier();
+    __asm__ volatile("" ::: "memory");
+}
+
 template <int RNG>
-__device__ bool mh_step(const SweepParams& p, const Tables& tab, ChainCtx& c, Mt& engine, Mt& gen,
-                        uint32_t v, double T, uint64_t gstep, uint32_t chain_gid) {
+__device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab, ChainCtx& c, Mt& engine, Mt& gen,
+                                        uint32_t v, uint32_t beg, uint32_t deg, uint32_t r, uint32_t nb_reg,
+                                        int lab_reg, double T, uint64_t gstep, uint32_t chain_gid, uint32_t* s_out) {
     const int lane = lane_id();
     const bool type_b = v >= c.na;
     const uint32_t K = c.K;
     const uint32_t k_own = type_b ? c.kb : c.ka, k_oth = type_b ? c.ka : c.kb;
     const uint32_t own_base = type_b ? c.ka : 0, oth_base = type_b ? 0 : c.ka;
-    const uint32_t beg = p.rowptr[v], end = p.rowptr[v + 1];
-    const uint32_t deg = end - beg;
-    const uint32_t r = c.labels[v];
     const uint32_t r_loc = r - own_base;
+    *s_out = r;
 
-    // ---- k_v: neighbour-label histogram over the CSR row (replaces the dense k_[v] row of
-    //      blockmodel.cc:691-700; labels gathered from HBM, counts reduced in LDS) ----
+    // ---- k_v: neighbour-label histogram of the CSR row (replaces the dense k_[v] row of
+    //      blockmodel.cc:691-700), reduced in LDS ----
     for (uint32_t t = lane; t < k_oth; t += kWave) c.hist[t] = 0;
-    __syncthreads();
-    int lab0 = 0;  // label of neighbour `lane` (first chunk), reused by the proposal
-    for (uint32_t j = lane; j < deg; j += kWave) {
-        const uint32_t nb = p.col[beg + j];
-        const int lab = c.labels[nb];
-        if (j < (uint32_t)kWave) lab0 = lab;
-        atomicAdd(&c.hist[lab - (int)oth_base], 1);
-    }
-    __syncthreads();
+    wave_fence();
+    if ((uint32_t)lane < deg) atomicAdd(&c.hist[lab_reg - (int)oth_base], 1);
+    for (uint32_t j = kWave + lane; j < deg; j += kWave)  // rows longer than one wave (rare)
+        atomicAdd(&c.hist[(int)c.labels[p.col[beg + j]] - (int)oth_base], 1);
+    wave_fence();
 
     // ---- proposal: single_vertex_change, blockmodel.cc:613-637 ----
     uint32_t s;
@@ -118,7 +125,7 @@ __device__ bool mh_step(const SweepParams& p, const Tables& tab, ChainCtx& c, Mt
         } else {
             uint32_t which = (uint32_t)(u_idx * (double)deg);
             if (which >= deg) which = deg - 1;
-            const uint32_t t = which < (uint32_t)kWave ? (uint32_t)bcast(lab0, (int)which)
+            const uint32_t t = which < (uint32_t)kWave ? (uint32_t)readlane(lab_reg, which)
                                                         : (uint32_t)c.labels[p.col[beg + which]];
             const int32_t mrt = c.mr[t];
             const double R_t = c.epsilon * (double)K / (mrt + c.epsilon * (double)K);
@@ -154,7 +161,7 @@ __device__ bool mh_step(const SweepParams& p, const Tables& tab, ChainCtx& c, Mt
             s = (uint32_t)(size_t)(engine.canonical() * (double)K);
         } else {
             const uint32_t which = (uint32_t)(size_t)(engine.canonical() * (double)deg);
-            const uint32_t t = which < (uint32_t)kWave ? (uint32_t)bcast(lab0, (int)which)
+            const uint32_t t = which < (uint32_t)kWave ? (uint32_t)readlane(lab_reg, which)
                                                         : (uint32_t)c.labels[p.col[beg + which]];
             const int32_t mrt = c.mr[t];
             const double R_t = c.epsilon * (double)K / (mrt + c.epsilon * (double)K);
@@ -177,7 +184,7 @@ __device__ bool mh_step(const SweepParams& p, const Tables& tab, ChainCtx& c, Mt
                     double cp = 0.;
                     const uint32_t cnt = (K - c0) < (uint32_t)kWave ? (K - c0) : (uint32_t)kWave;
                     for (uint32_t jj = 0; jj < cnt; ++jj) {
-                        const double pj = bcast(pr, (int)jj);
+                        const double pj = readlane(pr, jj);
                         acc = (c0 + jj == 0) ? pj : acc + pj;
                         if ((uint32_t)lane == jj) cp = acc;
                     }
@@ -191,10 +198,11 @@ __device__ bool mh_step(const SweepParams& p, const Tables& tab, ChainCtx& c, Mt
             }
         }
     }
+    *s_out = s;
 
     // ---- transition_ratio, metropolis_hasting.cc:103-192 ----
     double dS;
-    bool same = (r == s);
+    const bool same = (r == s);
     const bool cross = !same && ((r < c.ka) != (s < c.ka));
     if (same) {
         c.accu_r = 1.;  // :109-112
@@ -205,41 +213,87 @@ __device__ bool mh_step(const SweepParams& p, const Tables& tab, ChainCtx& c, Mt
         const uint32_t s_loc = s - own_base;
         const double Kd = (double)K;
         const double eps = c.epsilon;
+        const int ideg = (int)deg;
+        const int m0r = c.mr[r], m1r = m0r - ideg;
+        const int m0s = c.mr[s], m1s = m0s + ideg;
+        const int n_r_r = c.nr[r], n_r_s = c.nr[s];
+        const int eta_r = (int)c.eta[r * c.D + deg], eta_s = (int)c.eta[s * c.D + deg];
+
+        // (1) every table gather of the step is issued up front: the eight scalar-tail lgamma values
+        //     ride in lanes 0..7 of one wave-wide load ...
+        long long tail_idx = 1;
+        switch (lane) {
+            case 0: tail_idx = (long long)m0r + 1; break;    // :164
+            case 1: tail_idx = (long long)m0s + 1; break;    // :165
+            case 2: tail_idx = (long long)m1r + 1; break;    // :167
+            case 3: tail_idx = (long long)m1s + 1; break;    // :168
+            case 4: tail_idx = (long long)eta_r + 1; break;  // :173
+            case 5: tail_idx = (long long)eta_s + 1; break;  // :174
+            case 6: tail_idx = (long long)eta_r; break;      // :176  (eta_r - 1 + 1)
+            case 7: tail_idx = (long long)eta_s + 2; break;  // :177
+            default: break;
+        }
+        const double tail_lg = lgamma_fast(tab, tail_idx);
+
+        // ... and the per-block terms of the first 64 opposite-type blocks in lane t
+        struct Terms {
+            int k;
+            int32_t m_rt, m_st, mr_t;
+            double L1, L2, L3, L4;
+        };
+        auto load_terms = [&](uint32_t j) {
+            Terms t{0, 0, 0, 0, 0., 0., 0., 0.};
+            if (j < k_oth) t.k = c.hist[j];
+            if (t.k != 0) {
+                t.m_rt = Mx(c, type_b, r_loc, j);
+                t.m_st = Mx(c, type_b, s_loc, j);
+                t.mr_t = c.mr[oth_base + j];
+                t.L1 = lgamma_fast(tab, (long long)t.m_rt + 1);
+                t.L2 = lgamma_fast(tab, (long long)t.m_st + 1);
+                t.L3 = lgamma_fast(tab, (long long)t.m_rt - t.k + 1);
+                t.L4 = lgamma_fast(tab, (long long)t.m_st + t.k + 1);
+            }
+            return t;
+        };
+        Terms t0 = load_terms((uint32_t)lane);
+
+        // (2) while those loads are in flight: the four log_q values (:179-183), one per lane, in one
+        //     SIMT evaluation
+        int qn = 0, qk = 0;
+        if (lane == 0) { qn = m0r; qk = n_r_r; }
+        if (lane == 1) { qn = m0s; qk = n_r_s; }
+        if (lane == 2) { qn = m1r; qk = n_r_r - 1; }
+        if (lane == 3) { qn = m1s; qk = n_r_s + 1; }
+        const double lq = log_q(tab, qn, qk);
+
+        // (3) sums over opposite-type blocks (:150-163)
         double accu0 = 0., accu1 = 0., entropy0 = 0., entropy1 = 0.;
-        for (uint32_t c0 = 0; c0 < k_oth; c0 += kWave) {  // :150-163
-            const uint32_t j = c0 + lane;
-            int k = 0;
-            double A0 = 0., A1 = 0., L1 = 0., L2 = 0., L3 = 0., L4 = 0.;
-            if (j < k_oth) k = c.hist[j];
-            if (k != 0) {
-                const int32_t m_rt = Mx(c, type_b, r_loc, j), m_st = Mx(c, type_b, s_loc, j);
-                const int32_t mr_t = c.mr[oth_base + j];
-                A0 = k * (m_st + eps) / (mr_t + eps * Kd) / (int)deg;
-                A1 = k * (m_rt - k + eps) / (mr_t + eps * Kd) / (int)deg;
-                L1 = lgamma_fast(tab, (long long)m_rt + 1);
-                L2 = lgamma_fast(tab, (long long)m_st + 1);
-                L3 = lgamma_fast(tab, (long long)m_rt - k + 1);
-                L4 = lgamma_fast(tab, (long long)m_st + k + 1);
+        for (uint32_t c0 = 0; c0 < k_oth; c0 += kWave) {
+            const Terms t = (c0 == 0) ? t0 : load_terms(c0 + lane);
+            double A0 = 0., A1 = 0.;
+            if (t.k != 0) {
+                A0 = t.k * (t.m_st + eps) / (t.mr_t + eps * Kd) / ideg;
+                A1 = t.k * (t.m_rt - t.k + eps) / (t.mr_t + eps * Kd) / ideg;
             }
             if (RNG == RNG_PHILOX) {
                 // per-lane partial sums over chunks, reduced by the butterfly below
                 accu0 += A0;
                 accu1 += A1;
-                entropy0 -= L1;
-                entropy0 -= L2;
-                entropy1 -= L3;
-                entropy1 -= L4;
+                entropy0 -= t.L1;
+                entropy0 -= t.L2;
+                entropy1 -= t.L3;
+                entropy1 -= t.L4;
             } else {
                 // the reference's serial sums in ascending block index
                 const uint32_t cnt = (k_oth - c0) < (uint32_t)kWave ? (k_oth - c0) : (uint32_t)kWave;
                 for (uint32_t jj = 0; jj < cnt; ++jj) {
-                    if (bcast(k, (int)jj) == 0) continue;
-                    accu0 += bcast(A0, (int)jj);
-                    accu1 += bcast(A1, (int)jj);
-                    entropy0 -= bcast(L1, (int)jj);
-                    entropy0 -= bcast(L2, (int)jj);
-                    entropy1 -= bcast(L3, (int)jj);
-                    entropy1 -= bcast(L4, (int)jj);
+                    if (readlane(t.k, jj) == 0) continue;
+                    accu0 += readlane(A0, jj);
+                    accu1 += readlane(A1, jj);
+                    entropy0 -= readlane(t.L1, jj);
+                    entropy0 -= readlane(t.L2, jj);
+                    entropy1 -= readlane(t.L3, jj);
+                    entropy1 -= readlane(t.L4, jj);
                 }
             }
         }
@@ -249,23 +303,19 @@ __device__ bool mh_step(const SweepParams& p, const Tables& tab, ChainCtx& c, Mt
             entropy0 = butterfly_sum(entropy0);
             entropy1 = butterfly_sum(entropy1);
         }
-        const int ideg = (int)deg;
-        const int m0r = c.mr[r], m1r = m0r - ideg;
-        const int m0s = c.mr[s], m1s = m0s + ideg;
-        const int n_r_r = c.nr[r], n_r_s = c.nr[s];
-        const int eta_r = (int)c.eta[r * c.D + deg], eta_s = (int)c.eta[s * c.D + deg];
-        entropy0 -= -lgamma_fast(tab, (long long)m0r + 1);  // :164-168
-        entropy0 -= -lgamma_fast(tab, (long long)m0s + 1);
-        entropy1 -= -lgamma_fast(tab, (long long)m1r + 1);
-        entropy1 -= -lgamma_fast(tab, (long long)m1s + 1);
-        entropy0 += -lgamma_fast(tab, (long long)eta_r + 1);  // :173-177
-        entropy0 += -lgamma_fast(tab, (long long)eta_s + 1);
-        entropy1 += -lgamma_fast(tab, (long long)eta_r - 1 + 1);
-        entropy1 += -lgamma_fast(tab, (long long)eta_s + 1 + 1);
-        entropy0 += log_q(tab, m0r, n_r_r);  // :179-183
-        entropy0 += log_q(tab, m0s, n_r_s);
-        entropy1 += log_q(tab, m1r, n_r_r - 1);
-        entropy1 += log_q(tab, m1s, n_r_s + 1);
+        // (4) scalar tail in the reference's statement order
+        entropy0 -= -readlane(tail_lg, 0);  // :164-168
+        entropy0 -= -readlane(tail_lg, 1);
+        entropy1 -= -readlane(tail_lg, 2);
+        entropy1 -= -readlane(tail_lg, 3);
+        entropy0 += -readlane(tail_lg, 4);  // :173-177
+        entropy0 += -readlane(tail_lg, 5);
+        entropy1 += -readlane(tail_lg, 6);
+        entropy1 += -readlane(tail_lg, 7);
+        entropy0 += readlane(lq, 0);  // :179-183
+        entropy0 += readlane(lq, 1);
+        entropy1 += readlane(lq, 2);
+        entropy1 += readlane(lq, 3);
         c.accu_r = (deg == 0) ? 1. : accu1 / accu0;  // :185-189
         dS = entropy1 - entropy0;
     }
@@ -288,7 +338,7 @@ __device__ bool mh_step(const SweepParams& p, const Tables& tab, ChainCtx& c, Mt
     // ---- apply_mcmc_moves, blockmodel.cc:461-503 ----
     if (c.nr[r] - 1 == 0) return false;  // :467-471: a move that empties a block is vetoed after the draw
     if (same) return true;               // n_r, eta, m updates cancel; entropy_ += 0
-    __syncthreads();                     // all lanes have read nr/mr/eta before lane 0 rewrites them
+    wave_fence();                        // all lanes have read nr/mr/eta before lane 0 rewrites them
     if (lane == 0) {
         c.nr[r] -= 1;
         c.nr[s] += 1;
@@ -309,12 +359,18 @@ __device__ bool mh_step(const SweepParams& p, const Tables& tab, ChainCtx& c, Mt
         }
     }
     c.cum_dS += dS;  // :500
-    __syncthreads();
+    wave_fence();
     return true;
 }
 
 // ------------------------------------------------------------------------------------------
-// sweep kernel: metropolis_hasting::anneal (metropolis_hasting.cc:64-101), one wave per chain
+// sweep kernel: metropolis_hasting::anneal (metropolis_hasting.cc:64-101), one wave per chain.
+//
+// CSR staging: the visit order of a sweep is known in advance (a keyed permutation, or the shuffled
+// visit list), so everything that does not depend on the chain state is fetched ahead of use:
+//   * per 64 positions, lane q evaluates node v_q and loads its row extent and own label at once;
+//   * the neighbour ids of step q+2 and the neighbour labels of step q+1 are in flight while step q
+//     computes (labels fetched early are patched when step q moves one of those neighbours).
 // ------------------------------------------------------------------------------------------
 template <int RNG>
 __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
@@ -417,24 +473,59 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
         }
         const uint64_t current_step = num_nodes * sweep;  // :82
         for (uint64_t vi0 = 0; vi0 < num_nodes; vi0 += kWave) {
-            // each lane evaluates one position of the visit order; steps then run one by one
-            uint32_t v_lane = 0;
-            if (vi0 + lane < num_nodes)
-                v_lane = (RNG == RNG_COMPAT) ? vl[vi0 + lane] : order((uint32_t)(vi0 + lane));
+            // lane q: node, row extent and own label of position vi0 + q.  A node is visited once per
+            // sweep, so its own label cannot change before its step.
             const uint32_t cnt = (num_nodes - vi0) < (uint64_t)kWave ? (uint32_t)(num_nodes - vi0) : (uint32_t)kWave;
+            uint32_t v_l = 0, beg_l = 0, deg_l = 0, r_l = 0;
+            if ((uint32_t)lane < cnt) {
+                v_l = (RNG == RNG_COMPAT) ? vl[vi0 + lane] : order((uint32_t)(vi0 + lane));
+                beg_l = p.rowptr[v_l];
+                deg_l = p.rowptr[v_l + 1] - beg_l;
+                r_l = c.labels[v_l];
+            }
+            // pipeline prologue: ids + labels of step 0, ids of step 1
+            uint32_t nbC = 0xFFFFFFFFu, nbB = 0xFFFFFFFFu, nbA = 0xFFFFFFFFu;
+            int labC = 0, labB = 0;
+            {
+                const uint32_t b0 = readlane(beg_l, 0u), d0 = readlane(deg_l, 0u);
+                if ((uint32_t)lane < d0) {
+                    nbC = p.col[b0 + lane];
+                    labC = c.labels[nbC];
+                }
+                if (cnt > 1) {
+                    const uint32_t b1 = readlane(beg_l, 1u), d1 = readlane(deg_l, 1u);
+                    if ((uint32_t)lane < d1) nbB = p.col[b1 + lane];
+                }
+            }
             for (uint32_t q = 0; q < cnt; ++q) {
-                const uint32_t v = (uint32_t)__shfl((int)v_lane, (int)q, kWave);
+                const uint32_t v = readlane(v_l, q), beg = readlane(beg_l, q), deg = readlane(deg_l, q);
+                const uint32_t r = readlane(r_l, q);
+                // issue the prefetches of the next two steps
+                labB = 0;
+                if (nbB != 0xFFFFFFFFu) labB = c.labels[nbB];
+                nbA = 0xFFFFFFFFu;
+                if (q + 2 < cnt) {
+                    const uint32_t b2 = readlane(beg_l, q + 2), d2 = readlane(deg_l, q + 2);
+                    if ((uint32_t)lane < d2) nbA = p.col[b2 + lane];
+                }
                 const uint64_t vi = vi0 + q;
                 const double T = temperature(p, current_step + vi);  // :84
-                const bool ok = mh_step<RNG>(p, tab, c, engine, gen, v, T, sweeps_total * num_nodes + vi, chain_gid);
+                uint32_t s = r;
+                const bool ok = mh_step<RNG>(p, tab, c, engine, gen, v, beg, deg, r, nbC, labC, T,
+                                             sweeps_total * num_nodes + vi, chain_gid, &s);
                 if (ok) {  // :85-91
                     ++accepted_steps;
                     if (c.cum_dS < entropy_min) {
                         entropy_min = c.cum_dS;
                         u = 0;
                     }
+                    // the labels of step q+1 were requested before this move was written
+                    if (nbB == v) labB = (int)s;
                 }
                 if (T < 1.) ++u;  // :92-94
+                nbC = nbB;
+                labC = labB;
+                nbB = nbA;
             }
         }
         ++sweeps_total;
