@@ -67,7 +67,7 @@ ABI = {
     "bisbm_get_sizes": (C.c_int, [C.c_void_p, _u64p, _u64p, _u32p, _u32p]),
     "bisbm_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bisbm_last_sweep_timing": (C.c_int, [C.c_void_p, _f64p, _u64p]),
-    "bisbm_debug_log_q": (C.c_int, [C.c_void_p, _i32p, _i32p, C.c_size_t, _f64p]),
+    "bisbm_debug_log_q": (C.c_int, [C.c_void_p, _i32p, _i32p, C.c_size_t, C.c_int, _f64p]),
     "bisbm_io_read_edge_list": (C.c_long, [C.c_char_p, C.POINTER(_u64p), C.POINTER(_u64p)]),
     "bisbm_io_read_memberships": (C.c_long, [C.c_char_p, C.POINTER(_u32p)]),
     "bisbm_io_edges_to_csr": (C.c_int, [_u64p, _u64p, C.c_size_t, C.c_uint64, _u64p, _u32p]),
@@ -357,11 +357,12 @@ class BlockModel:
         self._check(self._L.bisbm_marginals_get(self._h, _p(out, _u32p)))
         return out
 
-    def debug_log_q(self, n, k):
+    def debug_log_q(self, n, k, fast=False):
         n = np.ascontiguousarray(n, dtype=np.int32)
         k = np.ascontiguousarray(k, dtype=np.int32)
         out = np.zeros(len(n), dtype=np.float64)
-        self._check(self._L.bisbm_debug_log_q(self._h, _p(n, _i32p), _p(k, _i32p), len(n), _p(out, _f64p)))
+        self._check(self._L.bisbm_debug_log_q(self._h, _p(n, _i32p), _p(k, _i32p), len(n), int(bool(fast)),
+                                              _p(out, _f64p)))
         return out
 
 

@@ -38,22 +38,44 @@ __device__ __forceinline__ double readlane(double x, uint32_t src) {
     return __hiloint2double(hi, lo);
 }
 
-// Fixed 64-leaf xor butterfly, levels 1,2,4,8,16,32: the summation tree of Philox mode.  FP add is
-// commutative, so every lane ends with the same bits.
-__device__ __forceinline__ double butterfly_sum(double x) {
-#pragma unroll
-    for (int lvl = 1; lvl < kWave; lvl <<= 1) x = x + __shfl_xor(x, lvl, kWave);
-    return x;
+// DPP controls (CDNA ISA): quad_perm, row_shr:n, row_mirror, row_half_mirror, row_bcast15/31
+constexpr int kDppXor1 = 0xB1;         // quad_perm:[1,0,3,2]
+constexpr int kDppXor2 = 0x4E;         // quad_perm:[2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;  // lane i <-> 7-i inside each group of 8
+constexpr int kDppMirror = 0x140;      // lane i <-> 15-i inside each row of 16
+constexpr int kDppBcast15 = 0x142;
+constexpr int kDppBcast31 = 0x143;
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
 }
 
-// inclusive prefix sum over the wave (int64 to be safe against 2^31 edge totals)
-__device__ __forceinline__ long long wave_inclusive_scan(long long x) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        long long y = __shfl_up(x, d, kWave);
-        if (lane >= d) x += y;
-    }
+// Fixed 64-leaf xor butterfly, levels 1,2,4,8,16,32: the summation tree of Philox mode (the CPU checker
+// restates the same tree).  Levels 1 and 2 are quad permutes; after them every lane of a quad holds
+// the quad's sum, so the mirror permutes pair the same partial sums as xor 4 / xor 8 would (FP add
+// is commutative: same bits); levels 16 and 32 add the four row sums as (R0+R1)+(R2+R3).  The
+// result is wave-uniform.
+__device__ __forceinline__ double butterfly_sum(double x) {
+    x = x + dpp_f64<kDppXor1>(x);
+    x = x + dpp_f64<kDppXor2>(x);
+    x = x + dpp_f64<kDppHalfMirror>(x);
+    x = x + dpp_f64<kDppMirror>(x);
+    const double r0 = readlane(x, 0u), r1 = readlane(x, 16u), r2 = readlane(x, 32u), r3 = readlane(x, 48u);
+    return (r0 + r1) + (r2 + r3);
+}
+
+// inclusive prefix sum of int32 over the wave: Kogge-Stone inside rows (row_shr), then the row
+// totals are carried with row_bcast15 / row_bcast31
+__device__ __forceinline__ int wave_inclusive_scan(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, kDppBcast15, 0xA, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, kDppBcast31, 0xC, 0xF, false);
     return x;
 }
 
@@ -302,17 +324,53 @@ __device__ inline double get_v(double u) {  // int_part.cc:77-87
     return v;
 }
 
+// log_q_approx, int_part.cc:89-98.
+//
+// Branch test `k < pow(n, 1/4.)` (:90) is evaluated as k^4 < n in integers: for n < 2^32 the
+// correctly rounded pow can equal an integer only when n is a perfect fourth power, and the distance
+// of n^(1/4) to the nearest integer is otherwise >= 1/(4 j^3) >> ulp, so the two tests agree.
+//
+// FAST (Philox mode only): for u = k/sqrt(n) > 21 every x = exp(-v) met by get_v is < 8e-10, where
+//   spence(x) = pi^2/6 - log(x) log1p(-x) - x P(-x)/Q(-x) = pi^2/6 - (v + 1) x + O(v x^2)
+// (log(x) = -v by construction, log1p(-x) = -x, P/Q = 1, all to below 1e-17 relative), hence
+//   u sqrt(spence) = u (pi/sqrt 6)(1 - (3/pi^2)(v + 1) x),
+// and in the closing formula log1p(-y) = -y, log(v/u) = log(pi/sqrt 6) - eps.  The iteration
+// itself (start v = u, stop when |dv| <= 1e-8) is kept, so the iteration count matches the literal
+// code.  Measured against the literal evaluation over u in [21, 60]: <= 4.6e-16 relative (3 ulp),
+// the size of the libm-to-libm differences the literal path has anyway.  Other arguments take the
+// literal path.
+template <bool FAST>
 __device__ inline double log_q_approx(const Tables& t, unsigned long long n, unsigned long long k) {
     const double kPi = 3.14159265358979323846;
-    if ((double)k < pow((double)n, 1 / 4.))  // int_part.cc:73-75,90-91
-        return lbinom_fast(t, n - 1, k - 1) - lgamma_fast(t, (long long)(k + 1));
-    const double u = (double)k / sqrt((double)n);  // int_part.cc:92-97
+    const bool small = k < 65536ull && (k * k) * (k * k) < n;  // int_part.cc:90
+    if (small) return lbinom_fast(t, n - 1, k - 1) - lgamma_fast(t, (long long)(k + 1));  // :73-75
+    const double sq = sqrt((double)n);
+    const double u = (double)k / sq;  // :92
+    if (FAST && u > 21.0) {
+        const double C0 = 0x1.48552f88091a8p+0;    // pi / sqrt(6)
+        const double C1 = 0x1.37423899a1558p-2;    // 3 / pi^2
+        const double LFC = -0x1.ef8383c50bb74p+0;  // log(pi/sqrt 6) - 1.5 log 2 - log pi
+        double v = u, x, eps, delta;
+        int guard = 0;
+        do {  // get_v, :77-87
+            x = exp(-v);
+            eps = C1 * (v + 1.0) * x;
+            const double n_v = u * (C0 * (1.0 - eps));
+            delta = fabs(n_v - v);
+            v = n_v;
+        } while (delta > 1e-8 && ++guard < 1000);
+        x = x * (1.0 - delta);  // exp(-v) after the last update: |v - v_prev| = delta <= 1e-8
+        const double lf = LFC - eps + 0.5 * x * (1.0 + u * u / 2);  // :94-95
+        const double g = 2 * v / u + u * x;                         // :96
+        return lf - log((double)n) + sq * g;                        // :97
+    }
     const double v = get_v(u);
     const double lf = log(v) - log1p(-exp(-v) * (1 + u * u / 2)) / 2 - log(2.) * 3 / 2. - log(u) - log(kPi);
     const double g = 2 * v / u - u * log1p(-exp(-v));
-    return lf - log((double)n) + sqrt((double)n) * g;
+    return lf - log((double)n) + sq * g;
 }
 
+template <bool FAST>
 __device__ inline double log_q(const Tables& t, int n, int k) {  // int_part.hh:27-37
     if (n <= 0 || k < 1) return 0;
     if (k > n) k = n;
@@ -320,7 +378,7 @@ __device__ inline double log_q(const Tables& t, int n, int k) {  // int_part.hh:
         if ((uint32_t)k >= t.q_stride) return NAN;  // outside the uploaded columns (cannot happen on the sweep path)
         return t.q[(size_t)n * t.q_stride + (size_t)k];
     }
-    return log_q_approx(t, (unsigned long long)n, (unsigned long long)k);
+    return log_q_approx<FAST>(t, (unsigned long long)n, (unsigned long long)k);
 }
 
 }  // namespace bisbm

@@ -113,8 +113,13 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
     uint32_t s;
     double u_acc = 0.;
     if (RNG == RNG_PHILOX) {
+#if defined(BISBM_ABLATE) && (BISBM_ABLATE & 2)
+        const uint32_t hsh = mix32((uint32_t)gstep ^ chain_gid);  // diagnostic build: Philox removed
+        const U4 A{hsh, hsh * 3u, hsh * 5u, hsh * 7u}, B{hsh * 11u, hsh * 13u, hsh * 17u, hsh * 19u};
+#else
         const U4 A = phx_draw(p.seed, chain_gid, PHX_STEP_A, gstep);
         const U4 B = phx_draw(p.seed, chain_gid, PHX_STEP_B, gstep);
+#endif
         const double u_idx = u53(A.x, A.y), u_R = u53(A.z, A.w), u_tgt = u53(B.x, B.y);
         u_acc = u53(B.z, B.w);
         if (k_own == 1) {
@@ -137,18 +142,19 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
                 long long x = (long long)(u_tgt * (double)mrt);
                 if (x >= (long long)mrt) x = (long long)mrt - 1;
                 const uint32_t t_loc = t - oth_base;
-                long long carry = 0;
+                long long carry = 0;  // row sums are < 2^31 (m_r is int32), so the in-wave scan is 32-bit
                 s = own_base + k_own - 1;
                 for (uint32_t c0 = 0; c0 < k_own; c0 += kWave) {
                     const uint32_t i = c0 + lane;
-                    const long long w = i < k_own ? (long long)Mx(c, type_b, i, t_loc) : 0;
-                    const long long cum = carry + wave_inclusive_scan(w);
+                    const int w = i < k_own ? Mx(c, type_b, i, t_loc) : 0;
+                    const int scan = wave_inclusive_scan(w);
+                    const long long cum = carry + (long long)scan;
                     const unsigned long long hit = __ballot(i < k_own && cum > x);
                     if (hit) {
                         s = own_base + c0 + (uint32_t)__ffsll((long long)hit) - 1;
                         break;
                     }
-                    carry = __shfl(cum, kWave - 1, kWave);
+                    carry += (long long)readlane(scan, (uint32_t)(kWave - 1));
                 }
             }
         }
@@ -264,7 +270,11 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
         if (lane == 1) { qn = m0s; qk = n_r_s; }
         if (lane == 2) { qn = m1r; qk = n_r_r - 1; }
         if (lane == 3) { qn = m1s; qk = n_r_s + 1; }
-        const double lq = log_q(tab, qn, qk);
+#if defined(BISBM_ABLATE) && (BISBM_ABLATE & 1)
+        const double lq = (double)(qn + qk) * 1e-9;  // diagnostic build: log_q removed (wrong results)
+#else
+        const double lq = log_q<RNG == RNG_PHILOX>(tab, qn, qk);
+#endif
 
         // (3) sums over opposite-type blocks (:150-163)
         double accu0 = 0., accu1 = 0., entropy0 = 0., entropy1 = 0.;
@@ -297,12 +307,14 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
                 }
             }
         }
+#if !(defined(BISBM_ABLATE) && (BISBM_ABLATE & 4))
         if (RNG == RNG_PHILOX) {
             accu0 = butterfly_sum(accu0);
             accu1 = butterfly_sum(accu1);
             entropy0 = butterfly_sum(entropy0);
             entropy1 = butterfly_sum(entropy1);
         }
+#endif
         // (4) scalar tail in the reference's statement order
         entropy0 -= -readlane(tail_lg, 0);  // :164-168
         entropy0 -= -readlane(tail_lg, 1);
@@ -693,7 +705,7 @@ __global__ __launch_bounds__(kWave) void entropy_kernel(EntropyParams p) {
     for (uint32_t i = lane; i < K * D; i += kWave) ent -= lgamma_fast(tab, (long long)eta_g[i] + 1);
     for (uint32_t r = lane; r < K; r += kWave) {
         ent += lgamma_fast(tab, (long long)mr_g[r] + 1);
-        ent += log_q(tab, mr_g[r], nr_g[r]);
+        ent += log_q<false>(tab, mr_g[r], nr_g[r]);
     }
     ent = butterfly_sum(ent);
     if (lane == 0) p.out[chain] = ent;
@@ -714,9 +726,10 @@ __global__ void marginals_kernel(MarginalParams p) {
     }
 }
 
-__global__ void log_q_probe_kernel(Tables tab, const int32_t* n, const int32_t* k, size_t count, double* out) {
+__global__ void log_q_probe_kernel(Tables tab, const int32_t* n, const int32_t* k, size_t count, double* out,
+                                   int fast) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < count) out[i] = log_q(tab, n[i], k[i]);
+    if (i < count) out[i] = fast ? log_q<true>(tab, n[i], k[i]) : log_q<false>(tab, n[i], k[i]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -784,9 +797,9 @@ hipError_t launch_marginals(const MarginalParams& p, hipStream_t stream) {
 }
 
 hipError_t launch_log_q_probe(const Tables& tab, const int32_t* n, const int32_t* k, size_t count, double* out,
-                              hipStream_t stream) {
+                              int fast, hipStream_t stream) {
     hipLaunchKernelGGL(log_q_probe_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, tab, n, k,
-                       count, out);
+                       count, out, fast);
     return hipGetLastError();
 }
 

@@ -109,6 +109,6 @@ hipError_t launch_shuffle(const ShuffleParams& p, int rng_mode, hipStream_t stre
 hipError_t launch_entropy(const EntropyParams& p, hipStream_t stream);
 hipError_t launch_marginals(const MarginalParams& p, hipStream_t stream);
 hipError_t launch_log_q_probe(const Tables& tab, const int32_t* n, const int32_t* k, size_t count, double* out,
-                              hipStream_t stream);
+                              int fast, hipStream_t stream);
 
 }  // namespace bisbm

@@ -758,7 +758,7 @@ int bisbm_last_sweep_timing(bisbm_handle h, double* kernel_ms, uint64_t* node_up
     return BISBM_OK;
 }
 
-int bisbm_debug_log_q(bisbm_handle h, const int32_t* n, const int32_t* k, size_t count, double* out) {
+int bisbm_debug_log_q(bisbm_handle h, const int32_t* n, const int32_t* k, size_t count, int fast, double* out) {
     if (!h) return BISBM_ERR_INVALID_ARG;
     if (!n || !k || !out) return fail(h, BISBM_ERR_INVALID_ARG, "NULL argument");
     if (count == 0) return BISBM_OK;
@@ -771,7 +771,7 @@ int bisbm_debug_log_q(bisbm_handle h, const int32_t* n, const int32_t* k, size_t
     HIPCHK(h, hipMemcpy(dn, n, sizeof(int32_t) * count, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(dk, k, sizeof(int32_t) * count, hipMemcpyHostToDevice));
     Tables tab{h->d_lgamma, h->tab->lg.size(), h->d_q, h->q_stride};
-    HIPCHK(h, launch_log_q_probe(tab, dn, dk, count, dout, h->stream));
+    HIPCHK(h, launch_log_q_probe(tab, dn, dk, count, dout, fast, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(out, dout, sizeof(double) * count, hipMemcpyDeviceToHost));
     (void)hipFree(dn);

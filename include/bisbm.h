@@ -135,8 +135,10 @@ int bisbm_set_stream(bisbm_handle h, void *hip_stream);
  * launch stream, and the number of node updates it executed (all chains). */
 int bisbm_last_sweep_timing(bisbm_handle h, double *kernel_ms, uint64_t *node_updates);
 
-/* Device numerics probe (tests): evaluates log_q(n[i], k[i]) on the device (int_part.hh:27-37). */
-int bisbm_debug_log_q(bisbm_handle h, const int32_t *n, const int32_t *k, size_t count,
+/* Device numerics probe (tests): evaluates log_q(n[i], k[i]) on the device (int_part.hh:27-37).
+ * fast = 0: the literal evaluation (mt19937-compat mode, entropy()); fast = 1: the Philox-mode
+ * evaluation, which uses a closed form of get_v/spence for k/sqrt(n) > 21. */
+int bisbm_debug_log_q(bisbm_handle h, const int32_t *n, const int32_t *k, size_t count, int fast,
                       double *out);
 
 const char *bisbm_last_error(bisbm_handle h); /* h may be NULL: error of the last failed create */

@@ -212,6 +212,12 @@ def test_device_log_q_matches_oracle():
     table = n < 10001
     assert (got[table] == want[table]).all()  # host-built table: same bits
     assert np.allclose(got[~table], want[~table], rtol=1e-12, atol=0)  # device libm vs glibc
+    # Philox-mode evaluation (closed form of get_v/spence for k/sqrt(n) > 21): a few ulp of the literal one
+    fast = g.debug_log_q(n, k, fast=True)
+    assert (fast[table] == want[table]).all()
+    assert np.allclose(fast[~table], want[~table], rtol=2e-15, atol=0)
+    u = k[~table] / np.sqrt(n[~table].astype(np.float64))
+    assert (u > 21).sum() > 300 and (u <= 21).sum() > 300  # both regimes are exercised
 
 
 def test_error_paths():
