@@ -260,6 +260,9 @@ struct Tables {
 };
 
 __device__ __forceinline__ double lgamma_fast(const Tables& t, long long x) {
+#if defined(BISBM_ABLATE) && (BISBM_ABLATE & 8)
+    return (double)x * 1e-3;  // diagnostic build: table gathers removed (wrong results)
+#endif
     if ((unsigned long long)x < t.lg_size) return t.lg[x];
     return NAN;  // the host sizes the table to cover every index the kernels can form (bisbm_create)
 }

@@ -24,7 +24,36 @@
 // are compared with (no FMA contraction).
 #include "bisbm_kernels.hpp"
 
+#include <cstdio>
+
 namespace bisbm {
+
+// In-kernel stamps (diagnostic builds only, -DBISBM_STAMPS): cycles per step segment, summed per
+// wave in scalar registers and added to g_stamps at kernel end.  Never enabled in the product build.
+#ifdef BISBM_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP_DECL unsigned long long st_prev = 0, st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP_START(stv)                                                    \
+    do {                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        __asm__ volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stv) :: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+    } while (0)
+#define STAMP(st, i)                                                        \
+    do {                                                                    \
+        unsigned long long now_;                                            \
+        STAMP_START(now_);                                                  \
+        (st).acc[i] += now_ - (st).prev;                                    \
+        (st).prev = now_;                                                   \
+    } while (0)
+struct Stamps {
+    unsigned long long prev;
+    unsigned long long acc[12];
+};
+#else
+struct Stamps {};
+#define STAMP(st, i) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // per-chain context held in registers / LDS while a sweep kernel runs
@@ -35,7 +64,9 @@ struct ChainCtx {
     int32_t* mr;     // K
     int32_t* nr;     // K
     int32_t* hist;   // max(ka, kb)
-    uint32_t* eta;   // K * (maxdeg+1), LDS or global
+    uint32_t* eta_l;  // K * (maxdeg+1) in LDS when it fits (eta_lds), else
+    uint32_t* eta_g;  // the chain's array in HBM
+    bool eta_lds;
     // global
     uint8_t* labels;
     // shape
@@ -46,6 +77,23 @@ struct ChainCtx {
     double cum_dS;
     double accu_r;
 };
+
+// eta lives in LDS or in HBM, chosen at compile time (template EL): one generic pointer would turn the
+// accesses into flat loads, which wait on vmcnt AND lgkmcnt and so drain the prefetch pipeline
+template <bool EL>
+__device__ __forceinline__ uint32_t eta_load(const ChainCtx& c, uint32_t idx) {
+    if constexpr (EL)
+        return c.eta_l[idx];
+    else
+        return c.eta_g[idx];
+}
+template <bool EL>
+__device__ __forceinline__ void eta_store(const ChainCtx& c, uint32_t idx, uint32_t val) {
+    if constexpr (EL)
+        c.eta_l[idx] = val;
+    else
+        c.eta_g[idx] = val;
+}
 
 // m[own block i][opposite block j] for a node of the given type, from the a x b quadrant
 __device__ __forceinline__ int32_t& Mx(const ChainCtx& c, bool type_b, uint32_t i_own, uint32_t j_oth) {
@@ -88,7 +136,7 @@ __device__ __forceinline__ void wave_fence() {
     __asm__ volatile("" ::: "memory");
 }
 
-template <int RNG>
+template <int RNG, bool EL>
 __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab, ChainCtx& c, Mt& engine, Mt& gen,
                                         uint32_t v, uint32_t beg, uint32_t deg, uint32_t r, uint32_t nb_reg,
                                         int lab_reg, double T, uint64_t gstep, uint32_t chain_gid, uint32_t* s_out) {
@@ -223,7 +271,7 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
         const int m0r = c.mr[r], m1r = m0r - ideg;
         const int m0s = c.mr[s], m1s = m0s + ideg;
         const int n_r_r = c.nr[r], n_r_s = c.nr[s];
-        const int eta_r = (int)c.eta[r * c.D + deg], eta_s = (int)c.eta[s * c.D + deg];
+        const int eta_r = (int)eta_load<EL>(c, r * c.D + deg), eta_s = (int)eta_load<EL>(c, s * c.D + deg);
 
         // (1) every table gather of the step is issued up front: the eight scalar-tail lgamma values
         //     ride in lanes 0..7 of one wave-wide load ...
@@ -354,8 +402,8 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
     if (lane == 0) {
         c.nr[r] -= 1;
         c.nr[s] += 1;
-        c.eta[r * c.D + deg] -= 1;
-        c.eta[s * c.D + deg] += 1;
+        eta_store<EL>(c, r * c.D + deg, eta_load<EL>(c, r * c.D + deg) - 1u);
+        eta_store<EL>(c, s * c.D + deg, eta_load<EL>(c, s * c.D + deg) + 1u);
         c.mr[r] -= (int)deg;
         c.mr[s] += (int)deg;
         c.labels[v] = (uint8_t)s;
@@ -376,6 +424,232 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
 }
 
 // ------------------------------------------------------------------------------------------
+// The same step, specialised for the common shape (Philox mode, both block counts <= 64, row <= 64
+// neighbours).  Every value it produces is the one mh_step<RNG_PHILOX> produces; tests run both.
+//   * no chunk loops; the k_v histogram comes from wave ballots (lane t keeps k_t in a register);
+//   * m_r and n_r are mirrored in registers (lane i <-> block i of each type), so their uniform reads
+//     are v_readlane instead of LDS round trips; LDS stays authoritative for the generic path;
+//   * the step's four uniforms arrive precomputed (one Philox evaluation per 64 steps per lane);
+//   * `prefetch` (the next steps' CSR/label loads) is issued AFTER this step's table gathers: vmcnt
+//     retires in order, so loads issued earlier would have to land before the gathers can be used.
+// ------------------------------------------------------------------------------------------
+struct BlockRegs {
+    int mrA, mrB, nrA, nrB;  // lane i: m_r / n_r of a-block i and of b-block i
+};
+
+template <bool EL, class Prefetch>
+__device__ __forceinline__ bool mh_step_fast(const SweepParams& p, const Tables& tab, ChainCtx& c, BlockRegs& br,
+                                             uint32_t v, uint32_t deg, uint32_t r, int lab_reg, double T,
+                                             double u_idx, double u_R, double u_tgt, double u_acc,
+                                             uint32_t nbits_a, uint32_t nbits_b, uint32_t* s_out,
+                                             Prefetch&& prefetch, Stamps& st) {
+    const int lane = lane_id();
+    const bool type_b = v >= c.na;
+    const uint32_t K = c.K;
+    const uint32_t k_own = type_b ? c.kb : c.ka, k_oth = type_b ? c.ka : c.kb;
+    const uint32_t own_base = type_b ? c.ka : 0, oth_base = type_b ? 0 : c.ka;
+    const uint32_t nbits = type_b ? nbits_a : nbits_b;  // bits of an opposite-type block index
+    const uint32_t r_loc = r - own_base;
+    const int mr_own = type_b ? br.mrB : br.mrA, mr_oth = type_b ? br.mrA : br.mrB;
+    const int nr_own = type_b ? br.nrB : br.nrA;
+    *s_out = r;
+
+    // early LDS reads that only need r: row r of m, eta[r][deg]
+    const int32_t m_rt = (uint32_t)lane < k_oth ? Mx(c, type_b, r_loc, (uint32_t)lane) : 0;
+    const int eta_r = (int)eta_load<EL>(c, r * c.D + deg);
+
+    STAMP(st, 0);  // loop overhead since the previous step's end
+    // ---- k_v by ballots: lane t ends with the mask of neighbours whose label is block t ----
+    const bool act = (uint32_t)lane < deg;
+    const uint32_t loc = (uint32_t)(lab_reg - (int)oth_base);
+    unsigned long long mask = __ballot(act);
+    for (uint32_t b = 0; b < nbits; ++b) {
+        const unsigned long long bb = __ballot(act && ((loc >> b) & 1u));
+        mask &= ((uint32_t)lane >> b) & 1u ? bb : ~bb;
+    }
+#if defined(BISBM_ABLATE) && (BISBM_ABLATE & 128)
+    const int k = ((uint32_t)lane < k_oth && act) ? 1 : 0;  // diagnostic: histogram removed
+#else
+    const int k = (uint32_t)lane < k_oth ? (int)__popcll(mask) : 0;
+#endif
+
+    STAMP(st, 1);  // histogram
+    // ---- proposal: single_vertex_change, blockmodel.cc:613-637 ----
+    uint32_t s;
+    if (k_own == 1) {
+        s = r;
+    } else if (deg == 0) {
+        s = (uint32_t)(u_idx * (double)K);
+        if (s >= K) s = K - 1;
+    } else {
+        uint32_t which = (uint32_t)(u_idx * (double)deg);
+        if (which >= deg) which = deg - 1;
+        const uint32_t t = (uint32_t)readlane(lab_reg, which);
+        const int32_t mrt = readlane(mr_oth, t - oth_base);
+        const double R_t = c.epsilon * (double)K / (mrt + c.epsilon * (double)K);
+#if defined(BISBM_ABLATE) && (BISBM_ABLATE & 256)
+        if (true) {  // diagnostic: discrete draw removed
+#else
+        if (u_R < R_t) {
+#endif
+            s = (uint32_t)(u_tgt * (double)K);
+            if (s >= K) s = K - 1;
+        } else {
+            long long x = (long long)(u_tgt * (double)mrt);
+            if (x >= (long long)mrt) x = (long long)mrt - 1;
+            const int w = (uint32_t)lane < k_own ? Mx(c, type_b, (uint32_t)lane, t - oth_base) : 0;
+            const int scan = wave_inclusive_scan(w);
+            const unsigned long long hit = __ballot((uint32_t)lane < k_own && (long long)scan > x);
+            s = hit ? own_base + (uint32_t)__ffsll((long long)hit) - 1 : own_base + k_own - 1;
+        }
+    }
+    *s_out = s;
+    STAMP(st, 2);  // proposal
+
+    // ---- transition_ratio, metropolis_hasting.cc:103-192 ----
+    double dS;
+    const bool same = (r == s);
+    const bool cross = !same && ((r < c.ka) != (s < c.ka));
+    if (same) {
+        c.accu_r = 1.;
+        dS = 0.;
+        prefetch();
+    } else if (cross) {
+        dS = INFINITY;
+        prefetch();
+    } else {
+        const uint32_t s_loc = s - own_base;
+        const double Kd = (double)K;
+        const double eps = c.epsilon;
+        const int ideg = (int)deg;
+        const int32_t m_st = (uint32_t)lane < k_oth ? Mx(c, type_b, s_loc, (uint32_t)lane) : 0;
+        const int eta_s = (int)eta_load<EL>(c, s * c.D + deg);
+        const int m0r = readlane(mr_own, r_loc), m1r = m0r - ideg;
+        const int m0s = readlane(mr_own, s_loc), m1s = m0s + ideg;
+        const int n_r_r = readlane(nr_own, r_loc), n_r_s = readlane(nr_own, s_loc);
+        long long tail_idx = 1;
+        switch (lane) {
+            case 0: tail_idx = (long long)m0r + 1; break;
+            case 1: tail_idx = (long long)m0s + 1; break;
+            case 2: tail_idx = (long long)m1r + 1; break;
+            case 3: tail_idx = (long long)m1s + 1; break;
+            case 4: tail_idx = (long long)eta_r + 1; break;
+            case 5: tail_idx = (long long)eta_s + 1; break;
+            case 6: tail_idx = (long long)eta_r; break;
+            case 7: tail_idx = (long long)eta_s + 2; break;
+            default: break;
+        }
+        const double tail_lg = lgamma_fast(tab, tail_idx);
+        double L1 = 0., L2 = 0., L3 = 0., L4 = 0.;
+        if (k != 0) {
+            L1 = lgamma_fast(tab, (long long)m_rt + 1);
+            L2 = lgamma_fast(tab, (long long)m_st + 1);
+            L3 = lgamma_fast(tab, (long long)m_rt - k + 1);
+            L4 = lgamma_fast(tab, (long long)m_st + k + 1);
+        }
+        STAMP(st, 3);  // LDS reads + gather issue
+        prefetch();  // younger than the gathers above: they can be consumed with vmcnt(#prefetch loads)
+        int qn = 0, qk = 0;
+        if (lane == 0) { qn = m0r; qk = n_r_r; }
+        if (lane == 1) { qn = m0s; qk = n_r_s; }
+        if (lane == 2) { qn = m1r; qk = n_r_r - 1; }
+        if (lane == 3) { qn = m1s; qk = n_r_s + 1; }
+#if defined(BISBM_ABLATE) && (BISBM_ABLATE & 1)
+        const double lq = (double)(qn + qk) * 1e-9;  // diagnostic build: log_q removed (wrong results)
+#else
+        const double lq = log_q<true>(tab, qn, qk);
+#endif
+        STAMP(st, 4);  // prefetch issue + log_q
+        double A0 = 0., A1 = 0.;
+        if (k != 0) {
+#if defined(BISBM_ABLATE) && (BISBM_ABLATE & 64)
+            A0 = k * (m_st + eps) * 1e-3;  // diagnostic: divisions removed
+            A1 = k * (m_rt - k + eps) * 1e-3;
+#else
+            A0 = k * (m_st + eps) / (mr_oth + eps * Kd) / ideg;
+            A1 = k * (m_rt - k + eps) / (mr_oth + eps * Kd) / ideg;
+#endif
+        }
+        double entropy0 = 0., entropy1 = 0.;
+        entropy0 -= L1;
+        entropy0 -= L2;
+        entropy1 -= L3;
+        entropy1 -= L4;
+        STAMP(st, 5);  // A0/A1 (waits for the gathers)
+        const double accu0 = butterfly_sum(A0);
+        const double accu1 = butterfly_sum(A1);
+        entropy0 = butterfly_sum(entropy0);
+        entropy1 = butterfly_sum(entropy1);
+        STAMP(st, 6);  // butterflies
+        entropy0 -= -readlane(tail_lg, 0u);
+        entropy0 -= -readlane(tail_lg, 1u);
+        entropy1 -= -readlane(tail_lg, 2u);
+        entropy1 -= -readlane(tail_lg, 3u);
+        entropy0 += -readlane(tail_lg, 4u);
+        entropy0 += -readlane(tail_lg, 5u);
+        entropy1 += -readlane(tail_lg, 6u);
+        entropy1 += -readlane(tail_lg, 7u);
+        entropy0 += readlane(lq, 0u);
+        entropy0 += readlane(lq, 1u);
+        entropy1 += readlane(lq, 2u);
+        entropy1 += readlane(lq, 3u);
+        c.accu_r = (deg == 0) ? 1. : accu1 / accu0;
+        dS = entropy1 - entropy0;
+    }
+
+    STAMP(st, 7);  // scalar tail
+    // ---- accept, metropolis_hasting.cc:47-61 ----
+    bool accept;
+    if (T == 0.) {
+        accept = dS < 0;
+    } else {
+#if defined(BISBM_ABLATE) && (BISBM_ABLATE & 32)
+        const double a = -1. / T * dS + (c.accu_r - 1.0);  // diagnostic: log/exp removed
+        accept = (a > 0.) ? true : (u_acc < 1.0 + a);
+#else
+        const double a = -1. / T * dS + log(c.accu_r);
+        accept = (a > 0.) ? true : (u_acc < exp(a));
+#endif
+    }
+    STAMP(st, 8);  // accept test
+    if (!accept) return false;
+
+    // ---- apply_mcmc_moves, blockmodel.cc:461-503 ----
+    if (readlane(nr_own, r_loc) - 1 == 0) return false;
+    if (same) return true;
+    wave_fence();
+    const uint32_t s_loc = s - own_base;
+    if (lane == 0) {
+        c.nr[r] -= 1;
+        c.nr[s] += 1;
+        eta_store<EL>(c, r * c.D + deg, eta_load<EL>(c, r * c.D + deg) - 1u);
+        eta_store<EL>(c, s * c.D + deg, eta_load<EL>(c, s * c.D + deg) + 1u);
+        c.mr[r] -= (int)deg;
+        c.mr[s] += (int)deg;
+        c.labels[v] = (uint8_t)s;
+    }
+    {
+        const int dm = ((uint32_t)lane == s_loc ? (int)deg : 0) - ((uint32_t)lane == r_loc ? (int)deg : 0);
+        const int dn = ((uint32_t)lane == s_loc ? 1 : 0) - ((uint32_t)lane == r_loc ? 1 : 0);
+        if (type_b) {
+            br.mrB += dm;
+            br.nrB += dn;
+        } else {
+            br.mrA += dm;
+            br.nrA += dn;
+        }
+    }
+    if (k != 0) {
+        Mx(c, type_b, r_loc, (uint32_t)lane) -= k;
+        Mx(c, type_b, s_loc, (uint32_t)lane) += k;
+    }
+    c.cum_dS += dS;
+    wave_fence();
+    STAMP(st, 9);  // apply
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
 // sweep kernel: metropolis_hasting::anneal (metropolis_hasting.cc:64-101), one wave per chain.
 //
 // CSR staging: the visit order of a sweep is known in advance (a keyed permutation, or the shuffled
@@ -384,7 +658,7 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
 //   * the neighbour ids of step q+2 and the neighbour labels of step q+1 are in flight while step q
 //     computes (labels fetched early are patched when step q moves one of those neighbours).
 // ------------------------------------------------------------------------------------------
-template <int RNG>
+template <int RNG, bool EL>
 __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const uint32_t chain = blockIdx.x;
@@ -406,13 +680,13 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
     cur += sizeof(int32_t) * K;
     c.hist = (int32_t*)cur;
     cur += sizeof(int32_t) * kmax;
+    uint32_t* ids_lds = (uint32_t*)cur;  // 64 rows x 64 neighbour ids of the current chunk
+    cur += sizeof(uint32_t) * kWave * kWave;
     uint32_t* eta_g = p.eta + (size_t)chain * K * D;
-    if (p.eta_in_lds) {
-        c.eta = (uint32_t*)cur;
-        cur += sizeof(uint32_t) * K * D;
-    } else {
-        c.eta = eta_g;
-    }
+    c.eta_g = eta_g;
+    c.eta_l = (uint32_t*)cur;
+    c.eta_lds = EL;
+    if (EL) cur += sizeof(uint32_t) * K * D;
     Mt engine{nullptr, 624}, gen{nullptr, 624};
     uint32_t* vl = nullptr;
     if (RNG == RNG_COMPAT) {
@@ -445,8 +719,8 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
         c.mr[i] = mr_g[i];
         c.nr[i] = nr_g[i];
     }
-    if (p.eta_in_lds)
-        for (uint32_t i = lane; i < K * D; i += kWave) c.eta[i] = eta_g[i];
+    if (EL)
+        for (uint32_t i = lane; i < K * D; i += kWave) c.eta_l[i] = eta_g[i];
     ChainScalars* sc = p.scalars + chain;
     if (RNG == RNG_COMPAT) {
         const uint32_t* eg = p.mt_engine + (size_t)chain * 624;
@@ -475,6 +749,22 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
     double entropy_min = INFINITY;  // :75
     double rate = 0.;
     bool stopped = false;
+    const bool fast_shape = (RNG == RNG_PHILOX) && p.ka <= (uint32_t)kWave && p.kb <= (uint32_t)kWave;
+    uint32_t nbits_a = 0, nbits_b = 0;  // bits needed for a block index of each type
+    while ((1u << nbits_a) < p.ka) ++nbits_a;
+    while ((1u << nbits_b) < p.kb) ++nbits_b;
+    Stamps st{};
+#ifdef BISBM_STAMPS
+    STAMP_START(st.prev);
+#endif
+    BlockRegs br{0, 0, 0, 0};
+    auto reload_block_regs = [&]() {
+        br.mrA = (uint32_t)lane < p.ka ? c.mr[lane] : 0;
+        br.nrA = (uint32_t)lane < p.ka ? c.nr[lane] : 0;
+        br.mrB = (uint32_t)lane < p.kb ? c.mr[p.ka + lane] : 0;
+        br.nrB = (uint32_t)lane < p.kb ? c.nr[p.ka + lane] : 0;
+    };
+    if (fast_shape) reload_block_regs();
 
     for (uint64_t sweep = 0; sweep < all_sweeps; ++sweep) {
         Feistel order;
@@ -485,6 +775,7 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
         }
         const uint64_t current_step = num_nodes * sweep;  // :82
         for (uint64_t vi0 = 0; vi0 < num_nodes; vi0 += kWave) {
+            // ---- chunk header: 64 positions of the visit order at once ----
             // lane q: node, row extent and own label of position vi0 + q.  A node is visited once per
             // sweep, so its own label cannot change before its step.
             const uint32_t cnt = (num_nodes - vi0) < (uint64_t)kWave ? (uint32_t)(num_nodes - vi0) : (uint32_t)kWave;
@@ -495,49 +786,97 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
                 deg_l = p.rowptr[v_l + 1] - beg_l;
                 r_l = c.labels[v_l];
             }
-            // pipeline prologue: ids + labels of step 0, ids of step 1
-            uint32_t nbC = 0xFFFFFFFFu, nbB = 0xFFFFFFFFu, nbA = 0xFFFFFFFFu;
-            int labC = 0, labB = 0;
-            {
-                const uint32_t b0 = readlane(beg_l, 0u), d0 = readlane(deg_l, 0u);
-                if ((uint32_t)lane < d0) {
-                    nbC = p.col[b0 + lane];
-                    labC = c.labels[nbC];
-                }
-                if (cnt > 1) {
-                    const uint32_t b1 = readlane(beg_l, 1u), d1 = readlane(deg_l, 1u);
-                    if ((uint32_t)lane < d1) nbB = p.col[b1 + lane];
-                }
+            // Philox mode: lane q also draws the four uniforms of step vi0 + q (counter-based: any lane can)
+            double ud_idx = 0., ud_R = 0., ud_tgt = 0., ud_acc = 0.;
+            if (RNG == RNG_PHILOX && fast_shape && (uint32_t)lane < cnt) {
+                const uint64_t gs = sweeps_total * num_nodes + vi0 + lane;
+                const U4 A = phx_draw(p.seed, chain_gid, PHX_STEP_A, gs);
+                const U4 B = phx_draw(p.seed, chain_gid, PHX_STEP_B, gs);
+                ud_idx = u53(A.x, A.y);
+                ud_R = u53(A.z, A.w);
+                ud_tgt = u53(B.x, B.y);
+                ud_acc = u53(B.z, B.w);
             }
+            // CSR staging: the chunk's 64 adjacency rows (first 64 ids of each) go HBM -> LDS by
+            // LDS-DMA, one 256-B row slot per instruction, all of them in flight together
+            wave_fence();
             for (uint32_t q = 0; q < cnt; ++q) {
+                const uint32_t b0 = readlane(beg_l, q), d0 = readlane(deg_l, q);
+                if ((uint32_t)lane < d0)
+                    __builtin_amdgcn_global_load_lds(p.col + b0 + lane, ids_lds + q * kWave, 4, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the DMA writes have landed before any ds_read
+            wave_fence();
+
+            // label pipeline: the labels of step q + kDepth are gathered while step q runs; moves made
+            // in between are replayed from a small ring when the stage is consumed
+            // The label load is unconditional (idle lanes read node 0): a register that receives loads must
+            // not also be written by VALU code, or the compiler drains vmcnt before that write.
+            auto gather = [&](uint32_t qq, uint32_t& nb, int& lab) {
+                if (qq < cnt) {
+                    const uint32_t d = readlane(deg_l, qq);
+                    const uint32_t id = ids_lds[qq * kWave + lane];
+                    const bool on = (uint32_t)lane < d;
+                    nb = on ? id : 0xFFFFFFFFu;
+                    lab = c.labels[on ? id : 0u];
+                }
+            };
+            // three stage registers in fixed roles (the loop is unrolled by the depth): a register that is
+            // the target of an in-flight load must never be copied, or the copy waits for the load
+            uint32_t nb1 = 0xFFFFFFFFu, nb2 = 0xFFFFFFFFu, nb3 = 0xFFFFFFFFu;
+            int lab1 = 0, lab2 = 0, lab3 = 0;
+            gather(0, nb1, lab1);
+            gather(1, nb2, lab2);
+            gather(2, nb3, lab3);
+            const uint32_t kNoMove = 0xFFFFFFFEu;
+            uint32_t mv_v1 = kNoMove, mv_v2 = kNoMove, mv_v3 = kNoMove;  // moves of steps q-3, q-2, q-1
+            int mv_s1 = 0, mv_s2 = 0, mv_s3 = 0;
+
+            auto do_step = [&](uint32_t q, uint32_t& nbS, int& labS) {
                 const uint32_t v = readlane(v_l, q), beg = readlane(beg_l, q), deg = readlane(deg_l, q);
                 const uint32_t r = readlane(r_l, q);
-                // issue the prefetches of the next two steps
-                labB = 0;
-                if (nbB != 0xFFFFFFFFu) labB = c.labels[nbB];
-                nbA = 0xFFFFFFFFu;
-                if (q + 2 < cnt) {
-                    const uint32_t b2 = readlane(beg_l, q + 2), d2 = readlane(deg_l, q + 2);
-                    if ((uint32_t)lane < d2) nbA = p.col[b2 + lane];
-                }
+                // this step's row: replay the moves made since its labels were requested
+                const uint32_t nbC = nbS;
+                int labC = labS;
+                if (nbC == mv_v1) labC = mv_s1;
+                if (nbC == mv_v2) labC = mv_s2;
+                if (nbC == mv_v3) labC = mv_s3;
+                auto prefetch = [&]() { gather(q + 3, nbS, labS); };  // the stage is free again: refill it
                 const uint64_t vi = vi0 + q;
                 const double T = temperature(p, current_step + vi);  // :84
                 uint32_t s = r;
-                const bool ok = mh_step<RNG>(p, tab, c, engine, gen, v, beg, deg, r, nbC, labC, T,
-                                             sweeps_total * num_nodes + vi, chain_gid, &s);
+                bool ok;
+                if (RNG == RNG_PHILOX && fast_shape && deg <= (uint32_t)kWave) {
+                    ok = mh_step_fast<EL>(p, tab, c, br, v, deg, r, labC, T, readlane(ud_idx, q), readlane(ud_R, q),
+                                      readlane(ud_tgt, q), readlane(ud_acc, q), nbits_a, nbits_b, &s, prefetch, st);
+                } else {
+                    prefetch();
+                    ok = mh_step<RNG, EL>(p, tab, c, engine, gen, v, beg, deg, r, nbC, labC, T,
+                                      sweeps_total * num_nodes + vi, chain_gid, &s);
+                    if (fast_shape && ok) reload_block_regs();
+                }
+                mv_v1 = mv_v2;
+                mv_s1 = mv_s2;
+                mv_v2 = mv_v3;
+                mv_s2 = mv_s3;
+                mv_v3 = kNoMove;
                 if (ok) {  // :85-91
                     ++accepted_steps;
                     if (c.cum_dS < entropy_min) {
                         entropy_min = c.cum_dS;
                         u = 0;
                     }
-                    // the labels of step q+1 were requested before this move was written
-                    if (nbB == v) labB = (int)s;
+                    if (s != r) {
+                        mv_v3 = v;
+                        mv_s3 = (int)s;
+                    }
                 }
                 if (T < 1.) ++u;  // :92-94
-                nbC = nbB;
-                labC = labB;
-                nbB = nbA;
+            };
+            for (uint32_t q = 0; q < cnt; q += 3) {
+                do_step(q, nb1, lab1);
+                if (q + 1 < cnt) do_step(q + 1, nb2, lab2);
+                if (q + 2 < cnt) do_step(q + 2, nb3, lab3);
             }
         }
         ++sweeps_total;
@@ -557,8 +896,8 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
         mr_g[i] = c.mr[i];
         nr_g[i] = c.nr[i];
     }
-    if (p.eta_in_lds)
-        for (uint32_t i = lane; i < K * D; i += kWave) eta_g[i] = c.eta[i];
+    if (EL)
+        for (uint32_t i = lane; i < K * D; i += kWave) eta_g[i] = c.eta_l[i];
     if (RNG == RNG_COMPAT) {
         uint32_t* eg = p.mt_engine + (size_t)chain * 624;
         uint32_t* gg = p.mt_gen + (size_t)chain * 624;
@@ -571,6 +910,10 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
             for (uint32_t i = lane; i < p.n; i += kWave) vg[i] = vl[i];
         }
     }
+#ifdef BISBM_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 12; ++i) atomicAdd(&g_stamps[i], st.acc[i]);
+#endif
     if (lane == 0) {
         sc->cum_dS = c.cum_dS;
         sc->accu_r = c.accu_r;
@@ -583,8 +926,10 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
     }
 }
 
-template __global__ void sweep_kernel<RNG_PHILOX>(SweepParams);
-template __global__ void sweep_kernel<RNG_COMPAT>(SweepParams);
+template __global__ void sweep_kernel<RNG_PHILOX, true>(SweepParams);
+template __global__ void sweep_kernel<RNG_PHILOX, false>(SweepParams);
+template __global__ void sweep_kernel<RNG_COMPAT, true>(SweepParams);
+template __global__ void sweep_kernel<RNG_COMPAT, false>(SweepParams);
 
 // ------------------------------------------------------------------------------------------
 // state build: init_bisbm (blockmodel.cc:682-688, compute_n_r :740-746, compute_m :702-714,
@@ -735,19 +1080,40 @@ __global__ void log_q_probe_kernel(Tables tab, const int32_t* n, const int32_t* 
 // ------------------------------------------------------------------------------------------
 // launchers (called from the host runtime)
 // ------------------------------------------------------------------------------------------
+template <int RNG, bool EL>
+static hipError_t launch_sweep_variant(const SweepParams& p, size_t lds_bytes, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)sweep_kernel<RNG, EL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((sweep_kernel<RNG, EL>), dim3(p.n_chains), dim3(kWave), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_sweep(const SweepParams& p, int rng_mode, size_t lds_bytes, hipStream_t stream) {
-    const dim3 grid(p.n_chains), block(kWave);
-    if (rng_mode == RNG_COMPAT) {
-        hipError_t e = hipFuncSetAttribute((const void*)sweep_kernel<RNG_COMPAT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(sweep_kernel<RNG_COMPAT>, grid, block, lds_bytes, stream, p);
-    } else {
-        hipError_t e = hipFuncSetAttribute((const void*)sweep_kernel<RNG_PHILOX>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(sweep_kernel<RNG_PHILOX>, grid, block, lds_bytes, stream, p);
+    hipError_t e;
+    if (rng_mode == RNG_COMPAT)
+        e = p.eta_in_lds ? launch_sweep_variant<RNG_COMPAT, true>(p, lds_bytes, stream)
+                         : launch_sweep_variant<RNG_COMPAT, false>(p, lds_bytes, stream);
+    else
+        e = p.eta_in_lds ? launch_sweep_variant<RNG_PHILOX, true>(p, lds_bytes, stream)
+                         : launch_sweep_variant<RNG_PHILOX, false>(p, lds_bytes, stream);
+    if (e != hipSuccess) return e;
+#ifdef BISBM_STAMPS
+    {
+        (void)hipStreamSynchronize(stream);
+        unsigned long long h[16] = {0};
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h));
+        const double steps = (double)p.n_chains * (double)(p.duration / p.n) * (double)p.n;
+        static const char* names[10] = {"loop", "hist", "proposal", "lds+gather issue", "prefetch+log_q", "A0/A1",
+                                        "butterfly", "tail", "accept", "apply"};
+        double tot = 0;
+        for (int i = 0; i < 10; ++i) tot += (double)h[i];
+        for (int i = 0; i < 10; ++i) fprintf(stderr, "[stamps] %-18s %8.1f cyc/step\n", names[i], (double)h[i] / steps);
+        fprintf(stderr, "[stamps] %-18s %8.1f cyc/step\n", "total", tot / steps);
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
     }
+#endif
     return hipGetLastError();
 }
 

@@ -561,9 +561,9 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     // LDS plan: m quadrant (odd row stride), m_r, n_r, k_v histogram; eta when it leaves room for
     // four chains per CU; compat adds the two mt19937 states and (small graphs) the visit list
     const size_t K = h->K, D = (size_t)h->maxdeg + 1, S = h->kb | 1u;
-    size_t lds = sizeof(int32_t) * (h->ka * S + 2 * K + std::max(h->ka, h->kb));
+    size_t lds = sizeof(int32_t) * (h->ka * S + 2 * K + std::max(h->ka, h->kb)) + sizeof(uint32_t) * 64 * 64;
     const size_t eta_bytes = sizeof(uint32_t) * K * D;
-    p.eta_in_lds = (lds + eta_bytes <= 36 * 1024) ? 1 : 0;
+    p.eta_in_lds = (lds + eta_bytes <= 40 * 1024) ? 1 : 0;
     if (p.eta_in_lds) lds += eta_bytes;
     p.vlist_in_lds = 0;
     if (h->rng_mode == BISBM_RNG_MT19937_COMPAT) {
