@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbisbm_hip.so")
-SOURCES = ["bisbm_kernels.hip", "bisbm_runtime.hip", "bisbm_io.cpp"]
+SOURCES = ["bisbm_kernels.hip", "bisbm_sweep_fast.hip", "bisbm_runtime.hip", "bisbm_io.cpp"]
 HEADERS = ["bisbm_device.hpp", "bisbm_kernels.hpp", os.path.join("..", "..", "include", "bisbm.h"),
            os.path.join("..", "..", "include", "bisbm_io.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",

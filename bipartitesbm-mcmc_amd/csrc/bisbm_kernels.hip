@@ -28,33 +28,6 @@
 
 namespace bisbm {
 
-// In-kernel stamps (diagnostic builds only, -DBISBM_STAMPS): cycles per step segment, summed per
-// wave in scalar registers and added to g_stamps at kernel end.  Never enabled in the product build.
-#ifdef BISBM_STAMPS
-__device__ unsigned long long g_stamps[16];
-#define STAMP_DECL unsigned long long st_prev = 0, st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define STAMP_START(stv)                                                    \
-    do {                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                  \
-        __asm__ volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stv) :: "memory"); \
-        __builtin_amdgcn_sched_barrier(0);                                  \
-    } while (0)
-#define STAMP(st, i)                                                        \
-    do {                                                                    \
-        unsigned long long now_;                                            \
-        STAMP_START(now_);                                                  \
-        (st).acc[i] += now_ - (st).prev;                                    \
-        (st).prev = now_;                                                   \
-    } while (0)
-struct Stamps {
-    unsigned long long prev;
-    unsigned long long acc[12];
-};
-#else
-struct Stamps {};
-#define STAMP(st, i) do { } while (0)
-#endif
-
 // ------------------------------------------------------------------------------------------
 // per-chain context held in registers / LDS while a sweep kernel runs
 // ------------------------------------------------------------------------------------------
@@ -98,27 +71,6 @@ __device__ __forceinline__ void eta_store(const ChainCtx& c, uint32_t idx, uint3
 // m[own block i][opposite block j] for a node of the given type, from the a x b quadrant
 __device__ __forceinline__ int32_t& Mx(const ChainCtx& c, bool type_b, uint32_t i_own, uint32_t j_oth) {
     return type_b ? c.mq[j_oth * c.S + i_own] : c.mq[i_own * c.S + j_oth];
-}
-
-__device__ __forceinline__ double temperature(const SweepParams& p, uint64_t t) {
-    switch (p.schedule) {  // metropolis_hasting.cc:10-37, arithmetic types as the C++ promotes them
-        case SCHED_CONSTANT:
-            return (double)p.kw0;
-        case SCHED_ABRUPT:
-            return ((float)t < p.kw0) ? 1. : 0.;
-        case SCHED_LINEAR:
-            return (double)(p.kw0 - p.kw1 * (float)t);
-        case SCHED_EXPONENTIAL:
-            if (t < p.T_len) return p.T_tab[t];  // host table: glibc pow, incl. the subnormal tail
-            if (p.T_zero_after) return 0.;
-            return (double)p.kw0 * pow((double)p.kw1, (double)t);
-        default: {  // SCHED_LOGARITHMIC
-            if (t < p.T_len) return p.T_tab[t];
-            const float x = (float)t + p.kw1;
-            const unsigned long long i = (unsigned long long)x;
-            return (double)p.kw0 / (i == 0 ? 0. : log((double)i));
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -181,8 +133,7 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
             const uint32_t t = which < (uint32_t)kWave ? (uint32_t)readlane(lab_reg, which)
                                                         : (uint32_t)c.labels[p.col[beg + which]];
             const int32_t mrt = c.mr[t];
-            const double R_t = c.epsilon * (double)K / (mrt + c.epsilon * (double)K);
-            if (u_R < R_t) {
+            if (u_R * (mrt + c.epsilon * (double)K) < c.epsilon * (double)K) {  // :622-624 without the division
                 s = (uint32_t)(u_tgt * (double)K);
                 if (s >= K) s = K - 1;
             } else {
@@ -256,6 +207,7 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
 
     // ---- transition_ratio, metropolis_hasting.cc:103-192 ----
     double dS;
+    double phx_accu0 = 1., phx_accu1 = 1.;
     const bool same = (r == s);
     const bool cross = !same && ((r < c.ka) != (s < c.ka));
     if (same) {
@@ -328,20 +280,20 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
         double accu0 = 0., accu1 = 0., entropy0 = 0., entropy1 = 0.;
         for (uint32_t c0 = 0; c0 < k_oth; c0 += kWave) {
             const Terms t = (c0 == 0) ? t0 : load_terms(c0 + lane);
-            double A0 = 0., A1 = 0.;
-            if (t.k != 0) {
-                A0 = t.k * (t.m_st + eps) / (t.mr_t + eps * Kd) / ideg;
-                A1 = t.k * (t.m_rt - t.k + eps) / (t.mr_t + eps * Kd) / ideg;
-            }
             if (RNG == RNG_PHILOX) {
-                // per-lane partial sums over chunks, reduced by the butterfly below
-                accu0 += A0;
-                accu1 += A1;
-                entropy0 -= t.L1;
-                entropy0 -= t.L2;
-                entropy1 -= t.L3;
-                entropy1 -= t.L4;
+                // production arithmetic (DESIGN.md "Philox-mode definition"): per-lane leaves over chunks
+                if (t.k != 0) {
+                    const double inv = 1.0 / (t.mr_t + eps * Kd);
+                    accu0 += t.k * (t.m_st + eps) * inv;
+                    accu1 += t.k * (t.m_rt - t.k + eps) * inv;
+                    entropy1 += (t.L1 + t.L2) - (t.L3 + t.L4);  // the leaf's share of dS = S1 - S0
+                }
             } else {
+                double A0 = 0., A1 = 0.;
+                if (t.k != 0) {
+                    A0 = t.k * (t.m_st + eps) / (t.mr_t + eps * Kd) / ideg;
+                    A1 = t.k * (t.m_rt - t.k + eps) / (t.mr_t + eps * Kd) / ideg;
+                }
                 // the reference's serial sums in ascending block index
                 const uint32_t cnt = (k_oth - c0) < (uint32_t)kWave ? (k_oth - c0) : (uint32_t)kWave;
                 for (uint32_t jj = 0; jj < cnt; ++jj) {
@@ -355,14 +307,16 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
                 }
             }
         }
-#if !(defined(BISBM_ABLATE) && (BISBM_ABLATE & 4))
         if (RNG == RNG_PHILOX) {
-            accu0 = butterfly_sum(accu0);
-            accu1 = butterfly_sum(accu1);
-            entropy0 = butterfly_sum(entropy0);
-            entropy1 = butterfly_sum(entropy1);
-        }
-#endif
+            // scalar terms folded into leaves 0..7 / 0..3 with their signs, then three butterflies
+            double d = entropy1;
+            const bool neg_tail = (lane < 2) || (lane >= 6);
+            if (lane < 8) d = d + (neg_tail ? -tail_lg : tail_lg);
+            if (lane < 4) d = d + (lane < 2 ? -lq : lq);
+            dS = butterfly_sum(d);
+            phx_accu0 = (deg == 0) ? 1. : butterfly_sum(accu0);
+            phx_accu1 = (deg == 0) ? 1. : butterfly_sum(accu1);
+        } else {
         // (4) scalar tail in the reference's statement order
         entropy0 -= -readlane(tail_lg, 0);  // :164-168
         entropy0 -= -readlane(tail_lg, 1);
@@ -376,22 +330,25 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
         entropy0 += readlane(lq, 1);
         entropy1 += readlane(lq, 2);
         entropy1 += readlane(lq, 3);
-        c.accu_r = (deg == 0) ? 1. : accu1 / accu0;  // :185-189
-        dS = entropy1 - entropy0;
+            c.accu_r = (deg == 0) ? 1. : accu1 / accu0;  // :185-189
+            dS = entropy1 - entropy0;
+        }
     }
 
     // ---- accept, metropolis_hasting.cc:47-61 ----
     bool accept;
-    if (T == 0.) {
+    if (RNG == RNG_PHILOX) {
+        if (cross)
+            accept = false;
+        else if (T == 0.)
+            accept = dS < 0;
+        else
+            accept = u_acc * phx_accu0 < phx_accu1 * exp(-dS / T);  // u < exp(-dS/T) accu1/accu0
+    } else if (T == 0.) {
         accept = dS < 0;
     } else {
         const double a = -1. / T * dS + log(c.accu_r);
-        if (a > 0.) {
-            accept = true;
-        } else {
-            const double u = (RNG == RNG_PHILOX) ? u_acc : engine.canonical();
-            accept = u < exp(a);
-        }
+        accept = (a > 0.) ? true : (engine.canonical() < exp(a));
     }
     if (!accept) return false;
 
@@ -420,232 +377,6 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
     }
     c.cum_dS += dS;  // :500
     wave_fence();
-    return true;
-}
-
-// ------------------------------------------------------------------------------------------
-// The same step, specialised for the common shape (Philox mode, both block counts <= 64, row <= 64
-// neighbours).  Every value it produces is the one mh_step<RNG_PHILOX> produces; tests run both.
-//   * no chunk loops; the k_v histogram comes from wave ballots (lane t keeps k_t in a register);
-//   * m_r and n_r are mirrored in registers (lane i <-> block i of each type), so their uniform reads
-//     are v_readlane instead of LDS round trips; LDS stays authoritative for the generic path;
-//   * the step's four uniforms arrive precomputed (one Philox evaluation per 64 steps per lane);
-//   * `prefetch` (the next steps' CSR/label loads) is issued AFTER this step's table gathers: vmcnt
-//     retires in order, so loads issued earlier would have to land before the gathers can be used.
-// ------------------------------------------------------------------------------------------
-struct BlockRegs {
-    int mrA, mrB, nrA, nrB;  // lane i: m_r / n_r of a-block i and of b-block i
-};
-
-template <bool EL, class Prefetch>
-__device__ __forceinline__ bool mh_step_fast(const SweepParams& p, const Tables& tab, ChainCtx& c, BlockRegs& br,
-                                             uint32_t v, uint32_t deg, uint32_t r, int lab_reg, double T,
-                                             double u_idx, double u_R, double u_tgt, double u_acc,
-                                             uint32_t nbits_a, uint32_t nbits_b, uint32_t* s_out,
-                                             Prefetch&& prefetch, Stamps& st) {
-    const int lane = lane_id();
-    const bool type_b = v >= c.na;
-    const uint32_t K = c.K;
-    const uint32_t k_own = type_b ? c.kb : c.ka, k_oth = type_b ? c.ka : c.kb;
-    const uint32_t own_base = type_b ? c.ka : 0, oth_base = type_b ? 0 : c.ka;
-    const uint32_t nbits = type_b ? nbits_a : nbits_b;  // bits of an opposite-type block index
-    const uint32_t r_loc = r - own_base;
-    const int mr_own = type_b ? br.mrB : br.mrA, mr_oth = type_b ? br.mrA : br.mrB;
-    const int nr_own = type_b ? br.nrB : br.nrA;
-    *s_out = r;
-
-    // early LDS reads that only need r: row r of m, eta[r][deg]
-    const int32_t m_rt = (uint32_t)lane < k_oth ? Mx(c, type_b, r_loc, (uint32_t)lane) : 0;
-    const int eta_r = (int)eta_load<EL>(c, r * c.D + deg);
-
-    STAMP(st, 0);  // loop overhead since the previous step's end
-    // ---- k_v by ballots: lane t ends with the mask of neighbours whose label is block t ----
-    const bool act = (uint32_t)lane < deg;
-    const uint32_t loc = (uint32_t)(lab_reg - (int)oth_base);
-    unsigned long long mask = __ballot(act);
-    for (uint32_t b = 0; b < nbits; ++b) {
-        const unsigned long long bb = __ballot(act && ((loc >> b) & 1u));
-        mask &= ((uint32_t)lane >> b) & 1u ? bb : ~bb;
-    }
-#if defined(BISBM_ABLATE) && (BISBM_ABLATE & 128)
-    const int k = ((uint32_t)lane < k_oth && act) ? 1 : 0;  // diagnostic: histogram removed
-#else
-    const int k = (uint32_t)lane < k_oth ? (int)__popcll(mask) : 0;
-#endif
-
-    STAMP(st, 1);  // histogram
-    // ---- proposal: single_vertex_change, blockmodel.cc:613-637 ----
-    uint32_t s;
-    if (k_own == 1) {
-        s = r;
-    } else if (deg == 0) {
-        s = (uint32_t)(u_idx * (double)K);
-        if (s >= K) s = K - 1;
-    } else {
-        uint32_t which = (uint32_t)(u_idx * (double)deg);
-        if (which >= deg) which = deg - 1;
-        const uint32_t t = (uint32_t)readlane(lab_reg, which);
-        const int32_t mrt = readlane(mr_oth, t - oth_base);
-        const double R_t = c.epsilon * (double)K / (mrt + c.epsilon * (double)K);
-#if defined(BISBM_ABLATE) && (BISBM_ABLATE & 256)
-        if (true) {  // diagnostic: discrete draw removed
-#else
-        if (u_R < R_t) {
-#endif
-            s = (uint32_t)(u_tgt * (double)K);
-            if (s >= K) s = K - 1;
-        } else {
-            long long x = (long long)(u_tgt * (double)mrt);
-            if (x >= (long long)mrt) x = (long long)mrt - 1;
-            const int w = (uint32_t)lane < k_own ? Mx(c, type_b, (uint32_t)lane, t - oth_base) : 0;
-            const int scan = wave_inclusive_scan(w);
-            const unsigned long long hit = __ballot((uint32_t)lane < k_own && (long long)scan > x);
-            s = hit ? own_base + (uint32_t)__ffsll((long long)hit) - 1 : own_base + k_own - 1;
-        }
-    }
-    *s_out = s;
-    STAMP(st, 2);  // proposal
-
-    // ---- transition_ratio, metropolis_hasting.cc:103-192 ----
-    double dS;
-    const bool same = (r == s);
-    const bool cross = !same && ((r < c.ka) != (s < c.ka));
-    if (same) {
-        c.accu_r = 1.;
-        dS = 0.;
-        prefetch();
-    } else if (cross) {
-        dS = INFINITY;
-        prefetch();
-    } else {
-        const uint32_t s_loc = s - own_base;
-        const double Kd = (double)K;
-        const double eps = c.epsilon;
-        const int ideg = (int)deg;
-        const int32_t m_st = (uint32_t)lane < k_oth ? Mx(c, type_b, s_loc, (uint32_t)lane) : 0;
-        const int eta_s = (int)eta_load<EL>(c, s * c.D + deg);
-        const int m0r = readlane(mr_own, r_loc), m1r = m0r - ideg;
-        const int m0s = readlane(mr_own, s_loc), m1s = m0s + ideg;
-        const int n_r_r = readlane(nr_own, r_loc), n_r_s = readlane(nr_own, s_loc);
-        long long tail_idx = 1;
-        switch (lane) {
-            case 0: tail_idx = (long long)m0r + 1; break;
-            case 1: tail_idx = (long long)m0s + 1; break;
-            case 2: tail_idx = (long long)m1r + 1; break;
-            case 3: tail_idx = (long long)m1s + 1; break;
-            case 4: tail_idx = (long long)eta_r + 1; break;
-            case 5: tail_idx = (long long)eta_s + 1; break;
-            case 6: tail_idx = (long long)eta_r; break;
-            case 7: tail_idx = (long long)eta_s + 2; break;
-            default: break;
-        }
-        const double tail_lg = lgamma_fast(tab, tail_idx);
-        double L1 = 0., L2 = 0., L3 = 0., L4 = 0.;
-        if (k != 0) {
-            L1 = lgamma_fast(tab, (long long)m_rt + 1);
-            L2 = lgamma_fast(tab, (long long)m_st + 1);
-            L3 = lgamma_fast(tab, (long long)m_rt - k + 1);
-            L4 = lgamma_fast(tab, (long long)m_st + k + 1);
-        }
-        STAMP(st, 3);  // LDS reads + gather issue
-        prefetch();  // younger than the gathers above: they can be consumed with vmcnt(#prefetch loads)
-        int qn = 0, qk = 0;
-        if (lane == 0) { qn = m0r; qk = n_r_r; }
-        if (lane == 1) { qn = m0s; qk = n_r_s; }
-        if (lane == 2) { qn = m1r; qk = n_r_r - 1; }
-        if (lane == 3) { qn = m1s; qk = n_r_s + 1; }
-#if defined(BISBM_ABLATE) && (BISBM_ABLATE & 1)
-        const double lq = (double)(qn + qk) * 1e-9;  // diagnostic build: log_q removed (wrong results)
-#else
-        const double lq = log_q<true>(tab, qn, qk);
-#endif
-        STAMP(st, 4);  // prefetch issue + log_q
-        double A0 = 0., A1 = 0.;
-        if (k != 0) {
-#if defined(BISBM_ABLATE) && (BISBM_ABLATE & 64)
-            A0 = k * (m_st + eps) * 1e-3;  // diagnostic: divisions removed
-            A1 = k * (m_rt - k + eps) * 1e-3;
-#else
-            A0 = k * (m_st + eps) / (mr_oth + eps * Kd) / ideg;
-            A1 = k * (m_rt - k + eps) / (mr_oth + eps * Kd) / ideg;
-#endif
-        }
-        double entropy0 = 0., entropy1 = 0.;
-        entropy0 -= L1;
-        entropy0 -= L2;
-        entropy1 -= L3;
-        entropy1 -= L4;
-        STAMP(st, 5);  // A0/A1 (waits for the gathers)
-        const double accu0 = butterfly_sum(A0);
-        const double accu1 = butterfly_sum(A1);
-        entropy0 = butterfly_sum(entropy0);
-        entropy1 = butterfly_sum(entropy1);
-        STAMP(st, 6);  // butterflies
-        entropy0 -= -readlane(tail_lg, 0u);
-        entropy0 -= -readlane(tail_lg, 1u);
-        entropy1 -= -readlane(tail_lg, 2u);
-        entropy1 -= -readlane(tail_lg, 3u);
-        entropy0 += -readlane(tail_lg, 4u);
-        entropy0 += -readlane(tail_lg, 5u);
-        entropy1 += -readlane(tail_lg, 6u);
-        entropy1 += -readlane(tail_lg, 7u);
-        entropy0 += readlane(lq, 0u);
-        entropy0 += readlane(lq, 1u);
-        entropy1 += readlane(lq, 2u);
-        entropy1 += readlane(lq, 3u);
-        c.accu_r = (deg == 0) ? 1. : accu1 / accu0;
-        dS = entropy1 - entropy0;
-    }
-
-    STAMP(st, 7);  // scalar tail
-    // ---- accept, metropolis_hasting.cc:47-61 ----
-    bool accept;
-    if (T == 0.) {
-        accept = dS < 0;
-    } else {
-#if defined(BISBM_ABLATE) && (BISBM_ABLATE & 32)
-        const double a = -1. / T * dS + (c.accu_r - 1.0);  // diagnostic: log/exp removed
-        accept = (a > 0.) ? true : (u_acc < 1.0 + a);
-#else
-        const double a = -1. / T * dS + log(c.accu_r);
-        accept = (a > 0.) ? true : (u_acc < exp(a));
-#endif
-    }
-    STAMP(st, 8);  // accept test
-    if (!accept) return false;
-
-    // ---- apply_mcmc_moves, blockmodel.cc:461-503 ----
-    if (readlane(nr_own, r_loc) - 1 == 0) return false;
-    if (same) return true;
-    wave_fence();
-    const uint32_t s_loc = s - own_base;
-    if (lane == 0) {
-        c.nr[r] -= 1;
-        c.nr[s] += 1;
-        eta_store<EL>(c, r * c.D + deg, eta_load<EL>(c, r * c.D + deg) - 1u);
-        eta_store<EL>(c, s * c.D + deg, eta_load<EL>(c, s * c.D + deg) + 1u);
-        c.mr[r] -= (int)deg;
-        c.mr[s] += (int)deg;
-        c.labels[v] = (uint8_t)s;
-    }
-    {
-        const int dm = ((uint32_t)lane == s_loc ? (int)deg : 0) - ((uint32_t)lane == r_loc ? (int)deg : 0);
-        const int dn = ((uint32_t)lane == s_loc ? 1 : 0) - ((uint32_t)lane == r_loc ? 1 : 0);
-        if (type_b) {
-            br.mrB += dm;
-            br.nrB += dn;
-        } else {
-            br.mrA += dm;
-            br.nrA += dn;
-        }
-    }
-    if (k != 0) {
-        Mx(c, type_b, r_loc, (uint32_t)lane) -= k;
-        Mx(c, type_b, s_loc, (uint32_t)lane) += k;
-    }
-    c.cum_dS += dS;
-    wave_fence();
-    STAMP(st, 9);  // apply
     return true;
 }
 
@@ -741,7 +472,7 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
     uint64_t sweeps_total = sc->sweeps_total;
     __syncthreads();
 
-    Tables tab{p.lgamma_tab, p.lgamma_size, p.q_tab, p.q_stride};
+    Tables tab{p.lgamma_tab, p.lgamma_size, p.q_tab, p.q_stride, p.log_tab};
     const uint32_t chain_gid = p.first_chain_id + chain;
     const uint64_t num_nodes = p.n;
     const uint64_t all_sweeps = p.duration / num_nodes;
@@ -749,23 +480,6 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
     double entropy_min = INFINITY;  // :75
     double rate = 0.;
     bool stopped = false;
-    const bool fast_shape = (RNG == RNG_PHILOX) && p.ka <= (uint32_t)kWave && p.kb <= (uint32_t)kWave;
-    uint32_t nbits_a = 0, nbits_b = 0;  // bits needed for a block index of each type
-    while ((1u << nbits_a) < p.ka) ++nbits_a;
-    while ((1u << nbits_b) < p.kb) ++nbits_b;
-    Stamps st{};
-#ifdef BISBM_STAMPS
-    STAMP_START(st.prev);
-#endif
-    BlockRegs br{0, 0, 0, 0};
-    auto reload_block_regs = [&]() {
-        br.mrA = (uint32_t)lane < p.ka ? c.mr[lane] : 0;
-        br.nrA = (uint32_t)lane < p.ka ? c.nr[lane] : 0;
-        br.mrB = (uint32_t)lane < p.kb ? c.mr[p.ka + lane] : 0;
-        br.nrB = (uint32_t)lane < p.kb ? c.nr[p.ka + lane] : 0;
-    };
-    if (fast_shape) reload_block_regs();
-
     for (uint64_t sweep = 0; sweep < all_sweeps; ++sweep) {
         Feistel order;
         if (RNG == RNG_COMPAT) {
@@ -785,17 +499,6 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
                 beg_l = p.rowptr[v_l];
                 deg_l = p.rowptr[v_l + 1] - beg_l;
                 r_l = c.labels[v_l];
-            }
-            // Philox mode: lane q also draws the four uniforms of step vi0 + q (counter-based: any lane can)
-            double ud_idx = 0., ud_R = 0., ud_tgt = 0., ud_acc = 0.;
-            if (RNG == RNG_PHILOX && fast_shape && (uint32_t)lane < cnt) {
-                const uint64_t gs = sweeps_total * num_nodes + vi0 + lane;
-                const U4 A = phx_draw(p.seed, chain_gid, PHX_STEP_A, gs);
-                const U4 B = phx_draw(p.seed, chain_gid, PHX_STEP_B, gs);
-                ud_idx = u53(A.x, A.y);
-                ud_R = u53(A.z, A.w);
-                ud_tgt = u53(B.x, B.y);
-                ud_acc = u53(B.z, B.w);
             }
             // CSR staging: the chunk's 64 adjacency rows (first 64 ids of each) go HBM -> LDS by
             // LDS-DMA, one 256-B row slot per instruction, all of them in flight together
@@ -843,18 +546,11 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
                 if (nbC == mv_v3) labC = mv_s3;
                 auto prefetch = [&]() { gather(q + 3, nbS, labS); };  // the stage is free again: refill it
                 const uint64_t vi = vi0 + q;
-                const double T = temperature(p, current_step + vi);  // :84
+                const double T = temperature_of(p, current_step + vi);  // :84
                 uint32_t s = r;
-                bool ok;
-                if (RNG == RNG_PHILOX && fast_shape && deg <= (uint32_t)kWave) {
-                    ok = mh_step_fast<EL>(p, tab, c, br, v, deg, r, labC, T, readlane(ud_idx, q), readlane(ud_R, q),
-                                      readlane(ud_tgt, q), readlane(ud_acc, q), nbits_a, nbits_b, &s, prefetch, st);
-                } else {
-                    prefetch();
-                    ok = mh_step<RNG, EL>(p, tab, c, engine, gen, v, beg, deg, r, nbC, labC, T,
-                                      sweeps_total * num_nodes + vi, chain_gid, &s);
-                    if (fast_shape && ok) reload_block_regs();
-                }
+                prefetch();
+                const bool ok = mh_step<RNG, EL>(p, tab, c, engine, gen, v, beg, deg, r, nbC, labC, T,
+                                                 sweeps_total * num_nodes + vi, chain_gid, &s);
                 mv_v1 = mv_v2;
                 mv_s1 = mv_s2;
                 mv_v2 = mv_v3;
@@ -910,10 +606,6 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
             for (uint32_t i = lane; i < p.n; i += kWave) vg[i] = vl[i];
         }
     }
-#ifdef BISBM_STAMPS
-    if (lane == 0)
-        for (int i = 0; i < 12; ++i) atomicAdd(&g_stamps[i], st.acc[i]);
-#endif
     if (lane == 0) {
         sc->cum_dS = c.cum_dS;
         sc->accu_r = c.accu_r;
@@ -1038,7 +730,7 @@ __global__ __launch_bounds__(kWave) void entropy_kernel(EntropyParams p) {
     const uint32_t chain = blockIdx.x;
     const int lane = lane_id();
     const uint32_t K = p.ka + p.kb, D = p.maxdeg + 1;
-    Tables tab{p.lgamma_tab, p.lgamma_size, p.q_tab, p.q_stride};
+    Tables tab{p.lgamma_tab, p.lgamma_size, p.q_tab, p.q_stride, p.log_tab};
     const int32_t* m_g = p.m + (size_t)chain * p.ka * p.kb;
     const int32_t* mr_g = p.m_r + (size_t)chain * K;
     const int32_t* nr_g = p.n_r + (size_t)chain * K;
@@ -1098,22 +790,6 @@ hipError_t launch_sweep(const SweepParams& p, int rng_mode, size_t lds_bytes, hi
         e = p.eta_in_lds ? launch_sweep_variant<RNG_PHILOX, true>(p, lds_bytes, stream)
                          : launch_sweep_variant<RNG_PHILOX, false>(p, lds_bytes, stream);
     if (e != hipSuccess) return e;
-#ifdef BISBM_STAMPS
-    {
-        (void)hipStreamSynchronize(stream);
-        unsigned long long h[16] = {0};
-        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h));
-        const double steps = (double)p.n_chains * (double)(p.duration / p.n) * (double)p.n;
-        static const char* names[10] = {"loop", "hist", "proposal", "lds+gather issue", "prefetch+log_q", "A0/A1",
-                                        "butterfly", "tail", "accept", "apply"};
-        double tot = 0;
-        for (int i = 0; i < 10; ++i) tot += (double)h[i];
-        for (int i = 0; i < 10; ++i) fprintf(stderr, "[stamps] %-18s %8.1f cyc/step\n", names[i], (double)h[i] / steps);
-        fprintf(stderr, "[stamps] %-18s %8.1f cyc/step\n", "total", tot / steps);
-        unsigned long long z[16] = {0};
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
-    }
-#endif
     return hipGetLastError();
 }
 

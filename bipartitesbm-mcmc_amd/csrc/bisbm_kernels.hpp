@@ -46,6 +46,7 @@ struct SweepParams {
     uint64_t lgamma_size;
     const double* q_tab;
     uint32_t q_stride;
+    const double* log_tab;
     const double* T_tab;  // host-evaluated temperatures for the pow/log schedules
     uint64_t T_len;
     int T_zero_after;
@@ -90,6 +91,7 @@ struct EntropyParams {
     uint64_t lgamma_size;
     const double* q_tab;
     uint32_t q_stride;
+    const double* log_tab;
     double* out;
 };
 
@@ -100,7 +102,30 @@ struct MarginalParams {
     uint32_t* counts;
 };
 
+// metropolis_hasting.cc:10-37, arithmetic types as the C++ promotes them
+__device__ __forceinline__ double temperature_of(const SweepParams& p, uint64_t t) {
+    switch (p.schedule) {
+        case SCHED_CONSTANT:
+            return (double)p.kw0;
+        case SCHED_ABRUPT:
+            return ((float)t < p.kw0) ? 1. : 0.;
+        case SCHED_LINEAR:
+            return (double)(p.kw0 - p.kw1 * (float)t);
+        case SCHED_EXPONENTIAL:
+            if (t < p.T_len) return p.T_tab[t];  // host table: glibc pow, incl. the subnormal tail
+            if (p.T_zero_after) return 0.;
+            return (double)p.kw0 * pow((double)p.kw1, (double)t);
+        default: {  // SCHED_LOGARITHMIC
+            if (t < p.T_len) return p.T_tab[t];
+            const float x = (float)t + p.kw1;
+            const unsigned long long i = (unsigned long long)x;
+            return (double)p.kw0 / (i == 0 ? 0. : log((double)i));
+        }
+    }
+}
+
 hipError_t launch_sweep(const SweepParams& p, int rng_mode, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_sweep_fast(const SweepParams& p, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_state_build(const BuildParams& p, hipStream_t stream);
 hipError_t launch_labels_broadcast(const uint32_t* src, uint8_t* labels, size_t label_stride, uint32_t n,
                                    uint32_t first_chain, uint32_t n_chains, hipStream_t stream);

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -33,6 +34,7 @@ thread_local std::string g_create_error;
 // ------------------------------------------------------------------------------------------
 struct HostTables {
     std::vector<double> lg;  // lg[i] = lgamma(i), lg[0] = +inf
+    std::vector<double> lo;  // lo[i] = log(i), lo[0] = 0 (safelog, cache.hh:38-44)
     std::vector<double> q;   // (10001) x (kcap+1)
     uint32_t kcap = 0;
 };
@@ -44,16 +46,20 @@ double log_sum(double a, double b) {  // int_part.cc:30-32
     return std::max(a, b) + std::log1p(std::exp(-std::fabs(a - b)));
 }
 
-void fill_lgamma(std::vector<double>& lg) {  // cache.cc:64-79
+void fill_lgamma(std::vector<double>& lg, std::vector<double>& lo) {  // cache.cc:64-79, :25-37
     const size_t n = lg.size();
     lg[0] = INFINITY;
+    lo[0] = 0.0;
     unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     if (n < (1u << 16)) nt = 1;
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nt; ++t) {
         th.emplace_back([&, t] {
             int sign;
-            for (size_t i = 1 + t; i < n; i += nt) lg[i] = lgamma_r((double)i, &sign);
+            for (size_t i = 1 + t; i < n; i += nt) {
+                lg[i] = lgamma_r((double)i, &sign);
+                lo[i] = std::log((double)i);
+            }
         });
     }
     for (auto& x : th) x.join();
@@ -111,7 +117,8 @@ std::shared_ptr<HostTables> get_tables(uint64_t lg_size, uint32_t kcap) {
             return kv.second;
     auto t = std::make_shared<HostTables>();
     t->lg.resize(lg_size);
-    fill_lgamma(t->lg);
+    t->lo.resize(lg_size);
+    fill_lgamma(t->lg, t->lo);
     t->kcap = kcap;
     t->q.resize((size_t)(kQNmax + 1) * ((size_t)kcap + 1));
     fill_q(t->q, kcap);
@@ -187,6 +194,7 @@ struct bisbm_engine {
     uint32_t* d_mt_engine = nullptr;
     uint32_t* d_mt_gen = nullptr;
     double* d_lgamma = nullptr;
+    double* d_logtab = nullptr;
     double* d_q = nullptr;
     double* d_T = nullptr;
     size_t d_T_cap = 0;
@@ -233,7 +241,7 @@ void free_all(bisbm_engine* h) {
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->d_rowptr, h->d_col,       h->d_labels, h->d_labels_tmp, h->d_vlist,     h->d_m,
                     h->d_m_r,    h->d_n_r,       h->d_eta,    h->d_scalars,    h->d_mt_engine, h->d_mt_gen,
-                    h->d_lgamma, h->d_q,         h->d_T,      h->d_tmp_f64,    h->d_stage_u32, h->d_counts};
+                    h->d_lgamma, h->d_logtab, h->d_q,         h->d_T,      h->d_tmp_f64,    h->d_stage_u32, h->d_counts};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -369,6 +377,7 @@ int bisbm_create(bisbm_handle* out, uint64_t n, uint64_t na, uint64_t nb, const 
     CCHK(dalloc(&h->d_eta, C * K * D));
     CCHK(dalloc(&h->d_scalars, C));
     CCHK(dalloc(&h->d_lgamma, h->tab->lg.size()));
+    CCHK(dalloc(&h->d_logtab, h->tab->lo.size()));
     CCHK(dalloc(&h->d_q, h->tab->q.size()));
     CCHK(dalloc(&h->d_tmp_f64, C));
     CCHK(dalloc(&h->d_stage_u32, n));
@@ -386,6 +395,7 @@ int bisbm_create(bisbm_handle* out, uint64_t n, uint64_t na, uint64_t nb, const 
         CCHK(hipMemcpy(h->d_rowptr, rp32.data(), sizeof(uint32_t) * (n + 1), hipMemcpyHostToDevice));
         if (nnz) CCHK(hipMemcpy(h->d_col, col, sizeof(uint32_t) * nnz, hipMemcpyHostToDevice));
         CCHK(hipMemcpy(h->d_lgamma, h->tab->lg.data(), sizeof(double) * h->tab->lg.size(), hipMemcpyHostToDevice));
+        CCHK(hipMemcpy(h->d_logtab, h->tab->lo.data(), sizeof(double) * h->tab->lo.size(), hipMemcpyHostToDevice));
         CCHK(hipMemcpy(h->d_q, h->tab->q.data(), sizeof(double) * h->tab->q.size(), hipMemcpyHostToDevice));
         CCHK(hipMemset(h->d_labels, 0, C * h->label_stride));
         std::vector<ChainScalars> sc(C);
@@ -529,6 +539,7 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     p.lgamma_size = h->tab->lg.size();
     p.q_tab = h->d_q;
     p.q_stride = h->q_stride;
+    p.log_tab = h->d_logtab;
     p.schedule = schedule;
     p.kw0 = kwargs[0];
     p.kw1 = kwargs[1];
@@ -577,7 +588,14 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     if (lds > 160 * 1024) return fail(h, BISBM_ERR_UNSUPPORTED, "chain state needs %zu B of LDS (> 160 KiB)", lds);
 
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    HIPCHK(h, launch_sweep(p, h->rng_mode, lds, h->stream));
+    // the production kernel covers Philox mode with both block counts <= 64; mt19937-compat mode and
+    // wider partitions run the generic kernel (BISBM_FORCE_GENERIC=1 forces it, for A/B checks)
+    const char* force = getenv("BISBM_FORCE_GENERIC");
+    const bool fast = h->rng_mode == BISBM_RNG_PHILOX && h->ka <= 64 && h->kb <= 64 && !(force && force[0] == '1');
+    if (fast)
+        HIPCHK(h, launch_sweep_fast(p, lds, h->stream));
+    else
+        HIPCHK(h, launch_sweep(p, h->rng_mode, lds, h->stream));
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     float ms = 0;
@@ -670,6 +688,7 @@ int bisbm_entropy(bisbm_handle h, double* out) {
     ep.lgamma_size = h->tab->lg.size();
     ep.q_tab = h->d_q;
     ep.q_stride = h->q_stride;
+    ep.log_tab = h->d_logtab;
     ep.out = h->d_tmp_f64;
     HIPCHK(h, launch_entropy(ep, h->stream));
     std::vector<double> part(h->n_chains);
@@ -770,7 +789,7 @@ int bisbm_debug_log_q(bisbm_handle h, const int32_t* n, const int32_t* k, size_t
     HIPCHK(h, dalloc(&dout, count));
     HIPCHK(h, hipMemcpy(dn, n, sizeof(int32_t) * count, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(dk, k, sizeof(int32_t) * count, hipMemcpyHostToDevice));
-    Tables tab{h->d_lgamma, h->tab->lg.size(), h->d_q, h->q_stride};
+    Tables tab{h->d_lgamma, h->tab->lg.size(), h->d_q, h->q_stride, h->d_logtab};
     HIPCHK(h, launch_log_q_probe(tab, dn, dk, count, dout, fast, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(out, dout, sizeof(double) * count, hipMemcpyDeviceToHost));

@@ -1,0 +1,447 @@
+// bisbm_sweep_fast.hip -- the production sweep kernel: Philox mode, both block counts <= 64.
+//
+// metropolis_hasting::anneal / step / transition_ratio (metropolis_hasting.cc:42-192),
+// single_vertex_change (blockmodel.cc:613-637) and apply_mcmc_moves (blockmodel.cc:461-503) for one
+// chain per wavefront, persistent over all sweeps of the call.  Every number it produces is the one
+// the generic kernel (bisbm_kernels.hip, sweep_kernel<RNG_PHILOX>) produces; the tests run both.
+//
+// What makes it the fast one:
+//   * state on chip: the a x b quadrant of m (odd row stride: rows and columns conflict-free) and
+//     eta in LDS; m_r and n_r mirrored in registers (lane i <-> block i of each type), so their
+//     wave-uniform reads are v_readlane, not LDS round trips;
+//   * CSR staged through LDS: per 64 positions of the visit order the 64 adjacency rows are pulled
+//     HBM -> LDS by LDS-DMA, all in flight together; neighbour labels are gathered three steps ahead
+//     into fixed stage registers (loop unrolled by the depth: a register that receives loads is never
+//     copied or written by VALU code, which would drain vmcnt), moves made meanwhile are replayed
+//     from a three-entry ring when a stage is consumed;
+//   * k_v from wave ballots (no LDS atomics); proposal CDF by a DPP scan; dS by DPP butterflies;
+//   * the four uniforms of a step come from one Philox evaluation per 64 steps per lane;
+//   * all table gathers of a step are issued together, the label prefetch right after them (vmcnt
+//     retires in order), and the log_q evaluation (four values in four lanes) runs under their latency;
+//   * no generic pointers (flat loads wait on vmcnt and lgkmcnt), no workgroup barriers on the step path;
+//   * apply_mcmc_moves writes values it already holds: no read-modify-write round trips.
+// Diagnostic hooks (BISBM_STAMPS) are compiled out of the product build.
+#include "bisbm_kernels.hpp"
+
+#include <cstdio>
+
+namespace bisbm {
+
+#ifdef BISBM_STAMPS
+__device__ unsigned long long g_fast_stamps[16];
+#define FSTAMP(i)                                                                                   \
+    do {                                                                                            \
+        unsigned long long now_;                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        __asm__ volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");            \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        st_acc[i] += now_ - st_prev;                                                                \
+        st_prev = now_;                                                                             \
+    } while (0)
+#else
+#define FSTAMP(i) \
+    do {          \
+    } while (0)
+#endif
+
+__device__ __forceinline__ void wfence() {
+    __builtin_amdgcn_wave_barrier();
+    __asm__ volatile("" ::: "memory");
+}
+
+// 8-byte table entry at a 32-bit element index: keeps the address in saddr + voffset form
+__device__ __forceinline__ double tab_at(const double* base, uint32_t idx) {
+    return *(const double*)((const char*)base + ((size_t)idx << 3));
+}
+
+template <bool EL, bool CT>
+__global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
+    extern __shared__ __align__(16) uint32_t lds32[];
+    const uint32_t chain = blockIdx.x;
+    if (chain >= p.n_chains) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t ka = p.ka, kb = p.kb, K = ka + kb, na = p.na;
+    const uint32_t D = p.maxdeg + 1, S = kb | 1u;
+    // LDS layout, dword offsets
+    const uint32_t o_mq = 0, o_mr = ka * S, o_nr = o_mr + K, o_eta = o_nr + K;
+    const uint32_t o_ids = o_eta + (EL ? K * D : 0u);
+    int32_t* const mq = (int32_t*)(lds32 + o_mq);
+    int32_t* const mr_l = (int32_t*)(lds32 + o_mr);
+    int32_t* const nr_l = (int32_t*)(lds32 + o_nr);
+    uint32_t* const eta_l = lds32 + o_eta;
+    uint32_t* const ids = lds32 + o_ids;
+
+    uint8_t* const labels = p.labels + (size_t)chain * p.label_stride;
+    int32_t* const m_g = p.m + (size_t)chain * ka * kb;
+    int32_t* const mr_g = p.m_r + (size_t)chain * K;
+    int32_t* const nr_g = p.n_r + (size_t)chain * K;
+    uint32_t* const eta_g = p.eta + (size_t)chain * K * D;
+    ChainScalars* const sc = p.scalars + chain;
+    const Tables tab{p.lgamma_tab, p.lgamma_size, p.q_tab, p.q_stride, p.log_tab};
+
+    // chain state -> LDS / registers
+    for (uint32_t i = lane; i < ka * kb; i += kWave) mq[(i / kb) * S + (i % kb)] = m_g[i];
+    for (uint32_t i = lane; i < K; i += kWave) {
+        mr_l[i] = mr_g[i];
+        nr_l[i] = nr_g[i];
+    }
+    if (EL)
+        for (uint32_t i = lane; i < K * D; i += kWave) eta_l[i] = eta_g[i];
+    __syncthreads();
+    int mrA = lane < ka ? mr_l[lane] : 0, nrA = lane < ka ? nr_l[lane] : 0;
+    int mrB = lane < kb ? mr_l[ka + lane] : 0, nrB = lane < kb ? nr_l[ka + lane] : 0;
+    double cum_dS = sc->cum_dS;
+    uint64_t sweeps_total = sc->sweeps_total;
+
+    auto eta_rd = [&](uint32_t idx) -> uint32_t { return EL ? eta_l[idx] : eta_g[idx]; };
+    auto eta_wr = [&](uint32_t idx, uint32_t val) {
+        if (EL)
+            eta_l[idx] = val;
+        else
+            eta_g[idx] = val;
+    };
+
+    const double eps = p.epsilon;
+    const double Kd = (double)K;
+    const double epsK = eps * Kd;
+    uint32_t nbits_a = 0, nbits_b = 0;  // bits of a block index of each type
+    while ((1u << nbits_a) < ka) ++nbits_a;
+    while ((1u << nbits_b) < kb) ++nbits_b;
+    const uint32_t chain_gid = p.first_chain_id + chain;
+    const uint32_t n = p.n;
+    const uint64_t all_sweeps = p.duration / n;
+    const double T_const = (double)p.kw0;  // CT: constant schedule (metropolis_hasting.cc:25-28)
+    uint64_t accepted_steps = 0, u_cnt = 0, sweeps_done = 0;
+    double entropy_min = INFINITY;  // metropolis_hasting.cc:75
+    double rate = 0.;
+    bool stopped = false;
+#ifdef BISBM_STAMPS
+    unsigned long long st_prev, st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    __asm__ volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
+
+    for (uint64_t sweep = 0; sweep < all_sweeps; ++sweep) {
+        Feistel order;
+        order.init(phx_draw(p.seed, chain_gid, PHX_SWEEP_KEY, sweeps_total), n);
+        const uint64_t sweep_step0 = (uint64_t)n * sweep;  // metropolis_hasting.cc:82
+        for (uint32_t vi0 = 0; vi0 < n; vi0 += kWave) {
+            // ---- chunk header: 64 positions of the visit order at once (lane q <-> position vi0+q) ----
+            const uint32_t cnt = (n - vi0) < (uint32_t)kWave ? (n - vi0) : (uint32_t)kWave;
+            uint32_t v_l = 0, beg_l = 0, deg_l = 0, r_l = 0;
+            double ud_idx = 0., ud_R = 0., ud_tgt = 0., ud_acc = 0.;
+            if (lane < cnt) {
+                v_l = order(vi0 + lane);
+                beg_l = p.rowptr[v_l];
+                deg_l = p.rowptr[v_l + 1] - beg_l;
+                r_l = labels[v_l];  // a node is visited once per sweep: its own label is stable until its step
+                const uint64_t gs = sweeps_total * (uint64_t)n + vi0 + lane;
+                const U4 A = phx_draw(p.seed, chain_gid, PHX_STEP_A, gs);
+                const U4 B = phx_draw(p.seed, chain_gid, PHX_STEP_B, gs);
+                ud_idx = u53(A.x, A.y);
+                ud_R = u53(A.z, A.w);
+                ud_tgt = u53(B.x, B.y);
+                ud_acc = u53(B.z, B.w);
+            }
+            // CSR staging: 64 rows (first 64 ids each) HBM -> LDS by LDS-DMA, one 256-B slot per instruction
+            wfence();
+            for (uint32_t q = 0; q < cnt; ++q) {
+                const uint32_t b0 = readlane(beg_l, q), d0 = readlane(deg_l, q);
+                if (lane < d0) __builtin_amdgcn_global_load_lds(p.col + b0 + lane, ids + q * kWave, 4, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0);  // the DMA writes have landed before any ds_read of ids
+            wfence();
+
+            // label pipeline (depth 3).  The label load is unconditional (idle lanes read node 0).
+            auto gather = [&](uint32_t qq, uint32_t& nb, int& lab) {
+                if (qq < cnt) {
+                    const uint32_t d = readlane(deg_l, qq);
+                    const uint32_t id = ids[qq * kWave + lane];
+                    const bool on = lane < d;
+                    nb = on ? id : 0xFFFFFFFFu;
+                    lab = labels[on ? id : 0u];
+                }
+            };
+            uint32_t nb1 = 0xFFFFFFFFu, nb2 = 0xFFFFFFFFu, nb3 = 0xFFFFFFFFu;
+            int lab1 = 0, lab2 = 0, lab3 = 0;
+            gather(0, nb1, lab1);
+            gather(1, nb2, lab2);
+            gather(2, nb3, lab3);
+            const uint32_t kNoMove = 0xFFFFFFFEu;
+            uint32_t mv_v1 = kNoMove, mv_v2 = kNoMove, mv_v3 = kNoMove;  // moves of steps q-3, q-2, q-1
+            int mv_s1 = 0, mv_s2 = 0, mv_s3 = 0;
+
+            auto do_step = [&](const uint32_t q, uint32_t& nbS, int& labS) {
+                FSTAMP(0);
+                const uint32_t v = readlane(v_l, q), deg = readlane(deg_l, q), r = readlane(r_l, q);
+                const bool type_b = v >= na;
+                const uint32_t k_own = type_b ? kb : ka, k_oth = type_b ? ka : kb;
+                const uint32_t own_base = type_b ? ka : 0u, oth_base = type_b ? 0u : ka;
+                const uint32_t nbits = type_b ? nbits_a : nbits_b;
+                const uint32_t r_loc = r - own_base;
+                const int mr_own = type_b ? mrB : mrA, mr_oth = type_b ? mrA : mrB;
+                const int nr_own = type_b ? nrB : nrA;
+                const double T = CT ? T_const : temperature_of(p, sweep_step0 + vi0 + q);  // :84
+                // m[own block i][opposite block j] from the a x b quadrant
+                auto mq_at = [&](uint32_t i_own, uint32_t j_oth) -> uint32_t {
+                    return type_b ? j_oth * S + i_own : i_own * S + j_oth;
+                };
+                // this step's row: replay the moves made since its labels were requested
+                const uint32_t nbC = nbS;
+                int labC = labS;
+                if (nbC == mv_v1) labC = mv_s1;
+                if (nbC == mv_v2) labC = mv_s2;
+                if (nbC == mv_v3) labC = mv_s3;
+                // early LDS reads that only need r
+                const uint32_t a_rt = mq_at(r_loc, lane);
+                const int32_t m_rt = lane < k_oth ? mq[a_rt] : 0;
+                const int eta_r = (int)eta_rd(r * D + deg);
+
+                // ---- k_v by ballots: lane t ends with the mask of neighbours whose label is block t ----
+                const bool act = lane < deg;
+                const uint32_t loc = (uint32_t)(labC - (int)oth_base);
+                unsigned long long mask = __ballot(act);
+#pragma unroll
+                for (uint32_t b = 0; b < 6; ++b) {
+                    if (b < nbits) {
+                        const unsigned long long bb = __ballot(act && ((loc >> b) & 1u));
+                        mask &= (lane >> b) & 1u ? bb : ~bb;
+                    }
+                }
+                int k = lane < k_oth ? (int)__popcll(mask) : 0;
+                if (deg > (uint32_t)kWave) {  // rows longer than one wave (rare): straight from HBM
+                    const uint32_t beg = readlane(beg_l, q);
+                    for (uint32_t j0 = kWave; j0 < deg; j0 += kWave) {
+                        const bool on = j0 + lane < deg;
+                        const uint32_t lc = on ? (uint32_t)labels[p.col[beg + j0 + lane]] - oth_base : 0u;
+                        unsigned long long m2 = __ballot(on);
+                        for (uint32_t b = 0; b < nbits; ++b) {
+                            const unsigned long long bb = __ballot(on && ((lc >> b) & 1u));
+                            m2 &= (lane >> b) & 1u ? bb : ~bb;
+                        }
+                        if (lane < k_oth) k += (int)__popcll(m2);
+                    }
+                }
+                FSTAMP(1);
+
+                // ---- proposal: single_vertex_change, blockmodel.cc:613-637 ----
+                const double u_idx = readlane(ud_idx, q);
+                uint32_t s;
+                if (k_own == 1) {
+                    s = r;
+                } else if (deg == 0) {
+                    s = (uint32_t)(u_idx * Kd);
+                    if (s >= K) s = K - 1;
+                } else {
+                    uint32_t which = (uint32_t)(u_idx * (double)deg);
+                    if (which >= deg) which = deg - 1;
+                    const uint32_t t = which < (uint32_t)kWave
+                                           ? (uint32_t)readlane(labC, which)
+                                           : (uint32_t)labels[p.col[readlane(beg_l, q) + which]];
+                    const int32_t mrt = readlane(mr_oth, t - oth_base);
+                    const double u_tgt = readlane(ud_tgt, q);
+                    if (readlane(ud_R, q) * (mrt + epsK) < epsK) {  // u < eps K / (m_r[t] + eps K), :622-624
+                        s = (uint32_t)(u_tgt * Kd);
+                        if (s >= K) s = K - 1;
+                    } else {  // integer inverse CDF over row m[t][.] restricted to v's own type (:627-628)
+                        long long x = (long long)(u_tgt * (double)mrt);
+                        if (x >= (long long)mrt) x = (long long)mrt - 1;
+                        const int w = lane < k_own ? mq[mq_at(lane, t - oth_base)] : 0;
+                        const int scan = wave_inclusive_scan(w);
+                        const unsigned long long hit = __ballot(lane < k_own && (long long)scan > x);
+                        s = hit ? own_base + (uint32_t)__ffsll((long long)hit) - 1 : own_base + k_own - 1;
+                    }
+                }
+                FSTAMP(2);
+
+                // ---- transition_ratio, metropolis_hasting.cc:103-192 (production arithmetic) ----
+                const bool same = (r == s);
+                const bool cross = !same && ((r < ka) != (s < ka));
+                bool accept;
+                double dS = 0.;
+                int32_t m_st = 0;
+                int eta_s = 0;
+                const uint32_t s_loc = s - own_base;
+                if (same || cross) {
+                    gather(q + 3, nbS, labS);
+                    accept = same && (T != 0.);  // r == s: a = 0, u < exp(0) always (:109-112); cross: dS = +inf
+                } else {
+                    const int ideg = (int)deg;
+                    const uint32_t a_st = mq_at(s_loc, lane);
+                    m_st = lane < k_oth ? mq[a_st] : 0;
+                    eta_s = (int)eta_rd(s * D + deg);
+                    const int m0r = readlane(mr_own, r_loc);
+                    const int m0s = readlane(mr_own, s_loc);
+                    const int n_r_r = readlane(nr_own, r_loc), n_r_s = readlane(nr_own, s_loc);
+                    // lanes 0..7: the scalar lgamma terms (:164-177); lanes 0..3 also carry the log_q arguments
+                    const bool odd = lane & 1u;
+                    const int mm = odd ? m0s : m0r;                      // lanes 0,1: m0r, m0s
+                    const int dd = (lane & 2u) ? (odd ? ideg : -ideg) : 0;  // lanes 2,3: m1r, m1s
+                    const int ee = odd ? eta_s : eta_r;
+                    const int eoff = lane < 6 ? 1 : (odd ? 2 : 0);  // eta_r+1, eta_s+1, eta_r, eta_s+2
+                    const uint32_t tail_idx = lane < 4 ? (uint32_t)(mm + dd + 1) : (uint32_t)(ee + eoff);
+                    const double tail_lg = lane < 8 ? tab_at(tab.lg, tail_idx) : 0.;
+                    double L1 = 0., L2 = 0., L3 = 0., L4 = 0.;
+                    if (k != 0) {
+                        L1 = tab_at(tab.lg, (uint32_t)(m_rt + 1));
+                        L2 = tab_at(tab.lg, (uint32_t)(m_st + 1));
+                        L3 = tab_at(tab.lg, (uint32_t)(m_rt - k + 1));
+                        L4 = tab_at(tab.lg, (uint32_t)(m_st + k + 1));
+                    }
+                    FSTAMP(3);
+                    gather(q + 3, nbS, labS);  // younger than the gathers above: vmcnt retires in order
+                    int qn = 0, qk = 0;
+                    if (lane < 4) {
+                        qn = mm + dd;
+                        qk = (odd ? n_r_s : n_r_r) + ((lane & 2u) ? (odd ? 1 : -1) : 0);
+                    }
+                    const double lq = log_q<true>(tab, qn, qk);
+                    FSTAMP(4);
+                    double a0 = 0., a1 = 0., d = 0.;
+                    if (k != 0) {
+                        const double inv = 1.0 / (mr_oth + epsK);
+                        a0 = k * (m_st + eps) * inv;
+                        a1 = k * (m_rt - k + eps) * inv;
+                        d = (L1 + L2) - (L3 + L4);
+                    }
+                    // fold the scalar terms into leaves 0..7 / 0..3 with their signs
+                    const bool neg_tail = (lane < 2) || (lane >= 6);  // -lg(m0r+1) -lg(m0s+1) ... -lg(eta_r) -lg(eta_s+2)
+                    if (lane < 8) d = d + (neg_tail ? -tail_lg : tail_lg);
+                    if (lane < 4) d = d + (lane < 2 ? -lq : lq);
+                    FSTAMP(5);
+                    dS = butterfly_sum(d);
+                    double accu0 = 1., accu1 = 1.;
+                    if (deg != 0) {
+                        accu0 = butterfly_sum(a0);
+                        accu1 = butterfly_sum(a1);
+                    }
+                    FSTAMP(6);
+                    // accept (:47-61): T == 0: dS < 0;  else u < exp(-dS/T) accu1/accu0
+                    if (T == 0.)
+                        accept = dS < 0;
+                    else
+                        accept = readlane(ud_acc, q) * accu0 < accu1 * exp(-dS / T);
+                }
+                FSTAMP(7);
+                // ---- apply_mcmc_moves, blockmodel.cc:461-503 ----
+                bool ok = accept && (readlane(nr_own, r_loc) - 1 != 0);  // :467-471 veto after the draw
+                uint32_t moved = kNoMove;
+                if (ok && !same) {
+                    wfence();
+                    const int ideg = (int)deg;
+                    if (lane == 0) {
+                        nr_l[r] = readlane(nr_own, r_loc) - 1;
+                        nr_l[s] = readlane(nr_own, s_loc) + 1;
+                        mr_l[r] = readlane(mr_own, r_loc) - ideg;
+                        mr_l[s] = readlane(mr_own, s_loc) + ideg;
+                        eta_wr(r * D + deg, (uint32_t)(eta_r - 1));
+                        eta_wr(s * D + deg, (uint32_t)(eta_s + 1));
+                        labels[v] = (uint8_t)s;
+                    }
+                    const int dm = (lane == s_loc ? ideg : 0) - (lane == r_loc ? ideg : 0);
+                    const int dn = (lane == s_loc ? 1 : 0) - (lane == r_loc ? 1 : 0);
+                    if (type_b) {
+                        mrB += dm;
+                        nrB += dn;
+                    } else {
+                        mrA += dm;
+                        nrA += dn;
+                    }
+                    if (k != 0) {
+                        mq[a_rt] = m_rt - k;
+                        mq[mq_at(s_loc, lane)] = m_st + k;
+                    }
+                    cum_dS += dS;  // :500
+                    moved = v;
+                    wfence();
+                }
+                FSTAMP(8);
+                // ---- bookkeeping of anneal(), metropolis_hasting.cc:85-94 ----
+                mv_v1 = mv_v2;
+                mv_s1 = mv_s2;
+                mv_v2 = mv_v3;
+                mv_s2 = mv_s3;
+                mv_v3 = moved;
+                mv_s3 = (int)s;
+                if (ok) ++accepted_steps;
+                if (!CT || T_const < 1.) {
+                    if (ok && cum_dS < entropy_min) {
+                        entropy_min = cum_dS;
+                        u_cnt = 0;
+                    }
+                    if (T < 1.) ++u_cnt;
+                }
+            };
+            for (uint32_t q = 0; q < cnt; q += 3) {
+                do_step(q, nb1, lab1);
+                if (q + 1 < cnt) do_step(q + 1, nb2, lab2);
+                if (q + 2 < cnt) do_step(q + 2, nb3, lab3);
+            }
+        }
+        ++sweeps_total;
+        sweeps_done = sweep + 1;
+        if (u_cnt >= p.steps_await) {  // metropolis_hasting.cc:96-98
+            rate = (double)accepted_steps / (double)((sweep + 1) * (uint64_t)n);
+            stopped = true;
+            break;
+        }
+    }
+    if (!stopped) rate = (double)accepted_steps / (double)p.duration;  // :100
+
+    // chain state -> HBM
+    __syncthreads();
+    for (uint32_t i = lane; i < ka * kb; i += kWave) m_g[i] = mq[(i / kb) * S + (i % kb)];
+    for (uint32_t i = lane; i < K; i += kWave) {
+        mr_g[i] = mr_l[i];
+        nr_g[i] = nr_l[i];
+    }
+    if (EL)
+        for (uint32_t i = lane; i < K * D; i += kWave) eta_g[i] = eta_l[i];
+#ifdef BISBM_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 12; ++i) atomicAdd(&g_fast_stamps[i], st_acc[i]);
+#endif
+    if (lane == 0) {
+        sc->cum_dS = cum_dS;
+        sc->sweeps_total = sweeps_total;
+        sc->last_rate = rate;
+        sc->last_accepted = accepted_steps;
+        sc->last_sweeps = sweeps_done;
+    }
+}
+
+template <bool EL, bool CT>
+static hipError_t launch_fast_variant(const SweepParams& p, size_t lds_bytes, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)sweep_fast_kernel<EL, CT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((sweep_fast_kernel<EL, CT>), dim3(p.n_chains), dim3(kWave), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_sweep_fast(const SweepParams& p, size_t lds_bytes, hipStream_t stream) {
+    const bool ct = p.schedule == SCHED_CONSTANT;
+    hipError_t e;
+    if (p.eta_in_lds)
+        e = ct ? launch_fast_variant<true, true>(p, lds_bytes, stream) : launch_fast_variant<true, false>(p, lds_bytes, stream);
+    else
+        e = ct ? launch_fast_variant<false, true>(p, lds_bytes, stream) : launch_fast_variant<false, false>(p, lds_bytes, stream);
+#ifdef BISBM_STAMPS
+    if (e == hipSuccess) {
+        (void)hipStreamSynchronize(stream);
+        unsigned long long h[16] = {0};
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fast_stamps), sizeof(h));
+        const double steps = (double)p.n_chains * (double)(p.duration / p.n) * (double)p.n;
+        static const char* names[9] = {"loop+consume", "hist", "proposal", "lds+gather issue", "prefetch+log_q",
+                                       "leaf terms", "butterflies", "accept", "apply"};
+        double tot = 0;
+        for (int i = 0; i < 9; ++i) tot += (double)h[i];
+        for (int i = 0; i < 9; ++i) fprintf(stderr, "[stamps] %-18s %8.1f cyc/step\n", names[i], (double)h[i] / steps);
+        fprintf(stderr, "[stamps] %-18s %8.1f cyc/step\n", "total", tot / steps);
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fast_stamps), z, sizeof(z));
+    }
+#endif
+    return e;
+}
+
+}  // namespace bisbm

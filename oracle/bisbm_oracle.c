@@ -586,6 +586,7 @@ struct orc_model {
     /* MH object state (metropolis_hasting.hh:26-28) */
     double entropy_min;
     double accu_r;
+    double phx_accu0, phx_accu1; /* Philox mode: the two Hastings sums of the last transition_ratio */
     /* rng */
     int rng_mode;
     orc_mt19937 engine, gen;
@@ -829,6 +830,7 @@ static double butterfly64(double *x) {
 static double transition_ratio(orc_model *m, size_t v, size_t r, size_t s) {
     if (r == s) { /* :109-112 */
         m->accu_r = 1.;
+        m->phx_accu0 = m->phx_accu1 = 1.;
         return 0.;
     }
     size_t KA = m->ka, K_ = m->K, D = m->max_degree + 1;
@@ -856,25 +858,44 @@ static double transition_ratio(orc_model *m, size_t v, size_t r, size_t s) {
             }
         }
     } else {
-        /* same terms; block j of the opposite type goes to leaf j mod 64, leaves are summed by
-         * the butterfly */
-        double a0[64] = {0}, a1[64] = {0}, e0[64] = {0}, e1[64] = {0};
+        /* Production (Philox-mode) arithmetic: the same quantities in a cheaper, wave-shaped form.
+         *   leaf l (0..63) collects the opposite-type blocks j with j mod 64 == l:
+         *     a0_l += k (m_st + eps) * inv_t,  a1_l += k (m_rt - k + eps) * inv_t,  inv_t = 1/(m_r[t] + eps K)
+         *       (the common factor 1/deg of :153-154 cancels in accu1/accu0 and is dropped)
+         *     d_l  += (lg(m_rt+1) + lg(m_st+1)) - (lg(m_rt-k+1) + lg(m_st+k+1))        (:155-158 as S1 - S0)
+         *   the eight scalar lgamma terms (:164-177) are folded into leaves 0..7 and the four log_q
+         *   terms (:179-183) into leaves 0..3, then each array is summed by the 64-leaf butterfly. */
+        double a0[64] = {0}, a1[64] = {0}, d[64] = {0};
         for (size_t t = t_lo; t < t_hi; ++t) {
             int k = m->kv[t];
             size_t leaf = (t - t_lo) & 63;
             if (k != 0) {
-                a0[leaf] += k * (m_row_s[t] + epsilon) / (m->m_r[t] + epsilon * K) / deg;
-                a1[leaf] += k * (m_row_r[t] - k + epsilon) / (m->m_r[t] + epsilon * K) / deg;
-                e0[leaf] -= orc_lgamma_fast((size_t)(m_row_r[t] + 1));
-                e0[leaf] -= orc_lgamma_fast((size_t)(m_row_s[t] + 1));
-                e1[leaf] -= orc_lgamma_fast((size_t)(m_row_r[t] - k + 1));
-                e1[leaf] -= orc_lgamma_fast((size_t)(m_row_s[t] + k + 1));
+                double inv = 1.0 / (m->m_r[t] + epsilon * K);
+                a0[leaf] += k * (m_row_s[t] + epsilon) * inv;
+                a1[leaf] += k * (m_row_r[t] - k + epsilon) * inv;
+                double L1 = orc_lgamma_fast((size_t)(m_row_r[t] + 1));
+                double L2 = orc_lgamma_fast((size_t)(m_row_s[t] + 1));
+                double L3 = orc_lgamma_fast((size_t)(m_row_r[t] - k + 1));
+                double L4 = orc_lgamma_fast((size_t)(m_row_s[t] + k + 1));
+                d[leaf] += (L1 + L2) - (L3 + L4);
             }
         }
-        accu0 = butterfly64(a0);
-        accu1 = butterfly64(a1);
-        entropy0 = butterfly64(e0);
-        entropy1 = butterfly64(e1);
+        d[0] = d[0] + -orc_lgamma_fast((size_t)(m0r + 1));
+        d[1] = d[1] + -orc_lgamma_fast((size_t)(m0s + 1));
+        d[2] = d[2] + orc_lgamma_fast((size_t)(m1r + 1));
+        d[3] = d[3] + orc_lgamma_fast((size_t)(m1s + 1));
+        d[4] = d[4] + orc_lgamma_fast((size_t)(eta_r + 1));
+        d[5] = d[5] + orc_lgamma_fast((size_t)(eta_s + 1));
+        d[6] = d[6] + -orc_lgamma_fast((size_t)(eta_r - 1 + 1));
+        d[7] = d[7] + -orc_lgamma_fast((size_t)(eta_s + 1 + 1));
+        d[0] = d[0] + -orc_log_q(m0r, n_r_r);
+        d[1] = d[1] + -orc_log_q(m0s, n_r_s);
+        d[2] = d[2] + orc_log_q(m1r, n_r_r - 1);
+        d[3] = d[3] + orc_log_q(m1s, n_r_s + 1);
+        m->phx_accu0 = deg == 0 ? 1. : butterfly64(a0);
+        m->phx_accu1 = deg == 0 ? 1. : butterfly64(a1);
+        m->accu_r = m->phx_accu1 / m->phx_accu0;
+        return butterfly64(d);
     }
     entropy0 -= -orc_lgamma_fast((size_t)(m0r + 1)); /* :164-168 */
     entropy0 -= -orc_lgamma_fast((size_t)(m0s + 1));
@@ -957,8 +978,8 @@ static size_t propose_philox(orc_model *m, size_t v, double u_idx, double u_R, d
     if (which >= d) which = d - 1;
     size_t j = m->col[m->rowptr[v] + which];
     size_t t = m->labels[j];
-    double R_t = m->epsilon * (double)K / (m->m_r[t] + m->epsilon * (double)K);
-    if (u_R < R_t) {
+    /* u < eps K / (m_r[t] + eps K)  <=>  u (m_r[t] + eps K) < eps K   (blockmodel.cc:622-624, no division) */
+    if (u_R * (m->m_r[t] + m->epsilon * (double)K) < m->epsilon * (double)K) {
         size_t s = (size_t)(u_tgt * (double)K);
         return s >= K ? K - 1 : s;
     }
@@ -1001,13 +1022,14 @@ static int step_philox(orc_model *m, size_t v, double temperature, uint64_t gste
     size_t r = m->labels[v];
     compute_kv(m, v);
     double dS = transition_ratio(m, v, r, s);
+    int cross = (r != s) && ((r < m->ka) != (s < m->ka));
+    if (cross) return 0; /* dS = +inf: never accepted (:121-123) */
     if (temperature == 0.) {
         if (dS < 0) return apply_mcmc_move(m, v, r, s, dS);
         return 0;
     }
-    double a = -1. / temperature * dS + log(m->accu_r);
-    if (a > 0.) return apply_mcmc_move(m, v, r, s, dS);
-    if (u_acc < exp(a)) return apply_mcmc_move(m, v, r, s, dS);
+    /* u < exp(-dS/T) accu1/accu0 (:54-57) written without the log and the quotient */
+    if (u_acc * m->phx_accu0 < m->phx_accu1 * exp(-dS / temperature)) return apply_mcmc_move(m, v, r, s, dS);
     return 0;
 }
 
