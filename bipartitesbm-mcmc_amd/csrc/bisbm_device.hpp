@@ -63,8 +63,21 @@ __device__ __forceinline__ double butterfly_sum(double x) {
     x = x + dpp_f64<kDppXor2>(x);
     x = x + dpp_f64<kDppHalfMirror>(x);
     x = x + dpp_f64<kDppMirror>(x);
-    const double r0 = readlane(x, 0u), r1 = readlane(x, 16u), r2 = readlane(x, 32u), r3 = readlane(x, 48u);
-    return (r0 + r1) + (r2 + r3);
+    // rows: R1 += R0, R3 += R2 (row_bcast15 into rows 1,3), then R3 += R1 (row_bcast31 into rows 2,3):
+    // lane 63 holds (R2+R3)+(R0+R1), the same tree as xor 16 / xor 32
+    {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), kDppBcast15, 0xA, 0xF, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), kDppBcast15, 0xA, 0xF, false);
+        const double y = __hiloint2double(hi, lo);
+        x = ((lane_id() >> 4) & 1) ? x + y : x;
+    }
+    {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), kDppBcast31, 0xC, 0xF, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), kDppBcast31, 0xC, 0xF, false);
+        const double y = __hiloint2double(hi, lo);
+        x = (lane_id() >= 32) ? x + y : x;
+    }
+    return readlane(x, 63u);
 }
 
 // inclusive prefix sum of int32 over the wave: Kogge-Stone inside rows (row_shr), then the row
@@ -344,7 +357,7 @@ __device__ inline double get_v(double u) {  // int_part.cc:77-87
 // the size of the libm-to-libm differences the literal path has anyway.  Other arguments take the
 // literal path.
 template <bool FAST>
-__device__ inline double log_q_approx(const Tables& t, unsigned long long n, unsigned long long k) {
+__device__ inline double log_q_approx(const Tables& t, unsigned long long n, unsigned long long k, double logn_pre) {
     const double kPi = 3.14159265358979323846;
     const bool small = k < 65536ull && (k * k) * (k * k) < n;  // int_part.cc:90
     if (small) return lbinom_fast(t, n - 1, k - 1) - lgamma_fast(t, (long long)(k + 1));  // :73-75
@@ -361,8 +374,7 @@ __device__ inline double log_q_approx(const Tables& t, unsigned long long n, uns
         const double x = exp(-C0 * u);
         const double eps = C1 * (C0 * u + 1.0) * x;
         const double corr = x * ((double)k + 0.5 * (1.0 + u * u / 2)) - eps * (2 * C0 * sq + 1.0);
-        const double logn = n < t.lg_size ? t.logtab[n] : log((double)n);
-        return (LFC - logn + 2 * C0 * sq) + corr;
+        return (LFC - logn_pre + 2 * C0 * sq) + corr;  // logn_pre = logtab[n], loaded by the caller with the other gathers
     }
     if (FAST && u > 21.0) {
         double v = u, x, eps, delta;
@@ -385,15 +397,16 @@ __device__ inline double log_q_approx(const Tables& t, unsigned long long n, uns
     return lf - log((double)n) + sq * g;
 }
 
+// logn_pre: log(n) from the host table when the caller has it already (FAST only), else unused
 template <bool FAST>
-__device__ inline double log_q(const Tables& t, int n, int k) {  // int_part.hh:27-37
+__device__ inline double log_q(const Tables& t, int n, int k, double logn_pre = 0.) {  // int_part.hh:27-37
     if (n <= 0 || k < 1) return 0;
     if (k > n) k = n;
     if (n < kQNmax + 1) {
         if ((uint32_t)k >= t.q_stride) return NAN;  // outside the uploaded columns (cannot happen on the sweep path)
         return t.q[(size_t)n * t.q_stride + (size_t)k];
     }
-    return log_q_approx<FAST>(t, (unsigned long long)n, (unsigned long long)k);
+    return log_q_approx<FAST>(t, (unsigned long long)n, (unsigned long long)k, logn_pre);
 }
 
 }  // namespace bisbm

@@ -273,7 +273,7 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
 #if defined(BISBM_ABLATE) && (BISBM_ABLATE & 1)
         const double lq = (double)(qn + qk) * 1e-9;  // diagnostic build: log_q removed (wrong results)
 #else
-        const double lq = log_q<RNG == RNG_PHILOX>(tab, qn, qk);
+        const double lq = log_q<RNG == RNG_PHILOX>(tab, qn, qk, (RNG == RNG_PHILOX && qn > 0 && (uint64_t)qn < tab.lg_size) ? tab.logtab[qn] : 0.);
 #endif
 
         // (3) sums over opposite-type blocks (:150-163)
@@ -343,7 +343,7 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
         else if (T == 0.)
             accept = dS < 0;
         else
-            accept = u_acc * phx_accu0 < phx_accu1 * exp(-dS / T);  // u < exp(-dS/T) accu1/accu0
+            accept = u_acc * phx_accu0 < phx_accu1 * exp(-dS * (1.0 / T));  // u < exp(-dS/T) accu1/accu0
     } else if (T == 0.) {
         accept = dS < 0;
     } else {
@@ -766,7 +766,12 @@ __global__ void marginals_kernel(MarginalParams p) {
 __global__ void log_q_probe_kernel(Tables tab, const int32_t* n, const int32_t* k, size_t count, double* out,
                                    int fast) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < count) out[i] = fast ? log_q<true>(tab, n[i], k[i]) : log_q<false>(tab, n[i], k[i]);
+    if (i < count) {
+        // the sweep kernels hand log(n) over from the host table; outside the table the probe uses the device log
+        const int nn = n[i];
+        const double logn = (nn > 0 && (uint64_t)nn < tab.lg_size) ? tab.logtab[nn] : log((double)(nn > 0 ? nn : 1));
+        out[i] = fast ? log_q<true>(tab, nn, k[i], logn) : log_q<false>(tab, nn, k[i]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -254,73 +254,70 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
                 FSTAMP(2);
 
                 // ---- transition_ratio, metropolis_hasting.cc:103-192 (production arithmetic) ----
+                // r == s (a = 0: always accepted at T > 0, :109-112) and cross-type targets (dS = +inf, :121-123)
+                // are rare; they run the same straight-line code with s replaced by r and the outcome
+                // overridden, so that the step has ONE prefetch site and no control-flow joins on registers
+                // that receive loads.
                 const bool same = (r == s);
                 const bool cross = !same && ((r < ka) != (s < ka));
-                bool accept;
-                double dS = 0.;
-                int32_t m_st = 0;
-                int eta_s = 0;
-                const uint32_t s_loc = s - own_base;
-                if (same || cross) {
-                    gather(q + 3, nbS, labS);
-                    accept = same && (T != 0.);  // r == s: a = 0, u < exp(0) always (:109-112); cross: dS = +inf
-                } else {
-                    const int ideg = (int)deg;
-                    const uint32_t a_st = mq_at(s_loc, lane);
-                    m_st = lane < k_oth ? mq[a_st] : 0;
-                    eta_s = (int)eta_rd(s * D + deg);
-                    const int m0r = readlane(mr_own, r_loc);
-                    const int m0s = readlane(mr_own, s_loc);
-                    const int n_r_r = readlane(nr_own, r_loc), n_r_s = readlane(nr_own, s_loc);
-                    // lanes 0..7: the scalar lgamma terms (:164-177); lanes 0..3 also carry the log_q arguments
-                    const bool odd = lane & 1u;
-                    const int mm = odd ? m0s : m0r;                      // lanes 0,1: m0r, m0s
-                    const int dd = (lane & 2u) ? (odd ? ideg : -ideg) : 0;  // lanes 2,3: m1r, m1s
-                    const int ee = odd ? eta_s : eta_r;
-                    const int eoff = lane < 6 ? 1 : (odd ? 2 : 0);  // eta_r+1, eta_s+1, eta_r, eta_s+2
-                    const uint32_t tail_idx = lane < 4 ? (uint32_t)(mm + dd + 1) : (uint32_t)(ee + eoff);
-                    const double tail_lg = lane < 8 ? tab_at(tab.lg, tail_idx) : 0.;
-                    double L1 = 0., L2 = 0., L3 = 0., L4 = 0.;
-                    if (k != 0) {
-                        L1 = tab_at(tab.lg, (uint32_t)(m_rt + 1));
-                        L2 = tab_at(tab.lg, (uint32_t)(m_st + 1));
-                        L3 = tab_at(tab.lg, (uint32_t)(m_rt - k + 1));
-                        L4 = tab_at(tab.lg, (uint32_t)(m_st + k + 1));
-                    }
-                    FSTAMP(3);
-                    gather(q + 3, nbS, labS);  // younger than the gathers above: vmcnt retires in order
-                    int qn = 0, qk = 0;
-                    if (lane < 4) {
-                        qn = mm + dd;
-                        qk = (odd ? n_r_s : n_r_r) + ((lane & 2u) ? (odd ? 1 : -1) : 0);
-                    }
-                    const double lq = log_q<true>(tab, qn, qk);
-                    FSTAMP(4);
-                    double a0 = 0., a1 = 0., d = 0.;
-                    if (k != 0) {
-                        const double inv = 1.0 / (mr_oth + epsK);
-                        a0 = k * (m_st + eps) * inv;
-                        a1 = k * (m_rt - k + eps) * inv;
-                        d = (L1 + L2) - (L3 + L4);
-                    }
-                    // fold the scalar terms into leaves 0..7 / 0..3 with their signs
-                    const bool neg_tail = (lane < 2) || (lane >= 6);  // -lg(m0r+1) -lg(m0s+1) ... -lg(eta_r) -lg(eta_s+2)
-                    if (lane < 8) d = d + (neg_tail ? -tail_lg : tail_lg);
-                    if (lane < 4) d = d + (lane < 2 ? -lq : lq);
-                    FSTAMP(5);
-                    dS = butterfly_sum(d);
-                    double accu0 = 1., accu1 = 1.;
-                    if (deg != 0) {
-                        accu0 = butterfly_sum(a0);
-                        accu1 = butterfly_sum(a1);
-                    }
-                    FSTAMP(6);
-                    // accept (:47-61): T == 0: dS < 0;  else u < exp(-dS/T) accu1/accu0
-                    if (T == 0.)
-                        accept = dS < 0;
-                    else
-                        accept = readlane(ud_acc, q) * accu0 < accu1 * exp(-dS / T);
+                const bool plain = !same && !cross;
+                const uint32_t s_eff = plain ? s : r;
+                const uint32_t s_loc = s_eff - own_base;
+                const int ideg = (int)deg;
+                const uint32_t a_st = mq_at(s_loc, lane);
+                const int32_t m_st = lane < k_oth ? mq[a_st] : 0;
+                const int eta_s = (int)eta_rd(s_eff * D + deg);
+                const int m0r = readlane(mr_own, r_loc);
+                const int m0s = readlane(mr_own, s_loc);
+                const int n_r_r = readlane(nr_own, r_loc), n_r_s = readlane(nr_own, s_loc);
+                // lanes 0..7: the scalar lgamma terms (:164-177); lanes 0..3 also carry the log_q arguments
+                const bool odd = lane & 1u;
+                const int mm = odd ? m0s : m0r;                         // lanes 0,1: m0r, m0s
+                const int dd = (lane & 2u) ? (odd ? ideg : -ideg) : 0;  // lanes 2,3: m1r, m1s
+                const int ee = odd ? eta_s : eta_r;
+                const int eoff = lane < 6 ? 1 : (odd ? 2 : 0);  // eta_r+1, eta_s+1, eta_r, eta_s+2
+                const uint32_t tail_idx = lane < 4 ? (uint32_t)(mm + dd + 1) : (lane < 8 ? (uint32_t)(ee + eoff) : 1u);
+                const int qn = lane < 4 ? mm + dd : 0;
+                const int qk = lane < 4 ? (odd ? n_r_s : n_r_r) + ((lane & 2u) ? (odd ? 1 : -1) : 0) : 0;
+                const double tail_lg = tab_at(tab.lg, tail_idx);
+                const double logn = tab_at(tab.logtab, (uint32_t)qn);  // log(n) of the four log_q arguments
+                const uint32_t kk = (uint32_t)k;
+                const double L1 = tab_at(tab.lg, (uint32_t)(m_rt + 1));
+                const double L2 = tab_at(tab.lg, (uint32_t)(m_st + 1));
+                const double L3 = tab_at(tab.lg, (uint32_t)(m_rt + 1) - kk);
+                const double L4 = tab_at(tab.lg, (uint32_t)(m_st + 1) + kk);
+                FSTAMP(3);
+                gather(q + 3, nbS, labS);  // younger than the gathers above: vmcnt retires in order
+                const double lq = log_q<true>(tab, qn, qk, logn);
+                FSTAMP(4);
+                double a0 = 0., a1 = 0., d = 0.;
+                if (k != 0) {
+                    const double inv = 1.0 / (mr_oth + epsK);
+                    a0 = k * (m_st + eps) * inv;
+                    a1 = k * (m_rt - k + eps) * inv;
+                    d = (L1 + L2) - (L3 + L4);
                 }
+                // fold the scalar terms into leaves 0..7 / 0..3 with their signs
+                const bool neg_tail = (lane < 2) || (lane >= 6);  // -lg(m0r+1) -lg(m0s+1) ... -lg(eta_r) -lg(eta_s+2)
+                if (lane < 8) d = d + (neg_tail ? -tail_lg : tail_lg);
+                if (lane < 4) d = d + (lane < 2 ? -lq : lq);
+                FSTAMP(5);
+                double dS = butterfly_sum(d);
+                double accu0 = butterfly_sum(a0);
+                double accu1 = butterfly_sum(a1);
+                if (deg == 0) accu0 = accu1 = 1.;
+                FSTAMP(6);
+                // accept (:47-61): T == 0: dS < 0;  else u < exp(-dS/T) accu1/accu0
+                bool accept;
+                if (T == 0.)
+                    accept = dS < 0;
+                else
+                    accept = readlane(ud_acc, q) * accu0 < accu1 * exp(-dS * (1.0 / T));
+                if (same) {
+                    accept = (T != 0.);
+                    dS = 0.;
+                }
+                if (cross) accept = false;
                 FSTAMP(7);
                 // ---- apply_mcmc_moves, blockmodel.cc:461-503 ----
                 bool ok = accept && (readlane(nr_own, r_loc) - 1 != 0);  // :467-471 veto after the draw
@@ -348,7 +345,7 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
                     }
                     if (k != 0) {
                         mq[a_rt] = m_rt - k;
-                        mq[mq_at(s_loc, lane)] = m_st + k;
+                        mq[a_st] = m_st + k;
                     }
                     cum_dS += dS;  // :500
                     moved = v;

@@ -1029,7 +1029,7 @@ static int step_philox(orc_model *m, size_t v, double temperature, uint64_t gste
         return 0;
     }
     /* u < exp(-dS/T) accu1/accu0 (:54-57) written without the log and the quotient */
-    if (u_acc * m->phx_accu0 < m->phx_accu1 * exp(-dS / temperature)) return apply_mcmc_move(m, v, r, s, dS);
+    if (u_acc * m->phx_accu0 < m->phx_accu1 * exp(-dS * (1.0 / temperature))) return apply_mcmc_move(m, v, r, s, dS);
     return 0;
 }
 
