@@ -341,6 +341,16 @@ __device__ inline double get_v(double u) {  // int_part.cc:77-87
     return v;
 }
 
+// exp(-y) to ~1e-7 relative for y in [0, 700]: f64 range reduction, v_exp_f32 on the fraction.
+// Used only where the value enters the result with a relative weight below 2e-9 (log_q tier u > 24:
+// every term that contains x = exp(-C0 u) is < 1.7e-9 of the result, so 1e-7 on x is < 2e-16 on it).
+__device__ __forceinline__ double exp_neg_lowprec(double y) {
+    const double t = -y * 0x1.71547652b82fep+0;  // * log2(e)
+    const double ti = rint(t);
+    const float f = (float)(t - ti);  // |f| <= 0.5
+    return ldexp((double)__builtin_amdgcn_exp2f(f), (int)ti);
+}
+
 // log_q_approx, int_part.cc:89-98.
 //
 // Branch test `k < pow(n, 1/4.)` (:90) is evaluated as k^4 < n in integers: for n < 2^32 the
@@ -371,7 +381,7 @@ __device__ inline double log_q_approx(const Tables& t, unsigned long long n, uns
         // eps = C1 (C0 u + 1) x, x = exp(-C0 u) (the first iterate's own correction changes x by
         // < 1e-8 relative, i.e. the result by < 1e-17).  log(n) comes from the host-built table.
         // Measured against the literal evaluation for u in [24, 70], n up to 6e7: <= 5.6e-16 relative.
-        const double x = exp(-C0 * u);
+        const double x = exp_neg_lowprec(C0 * u);  // x only feeds terms of relative weight < 2e-9 (see below)
         const double eps = C1 * (C0 * u + 1.0) * x;
         const double corr = x * ((double)k + 0.5 * (1.0 + u * u / 2)) - eps * (2 * C0 * sq + 1.0);
         return (LFC - logn_pre + 2 * C0 * sq) + corr;  // logn_pre = logtab[n], loaded by the caller with the other gathers

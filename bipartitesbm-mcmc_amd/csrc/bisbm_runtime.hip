@@ -363,6 +363,7 @@ int bisbm_create(bisbm_handle* out, uint64_t n, uint64_t na, uint64_t nb, const 
     uint64_t lg_size = 2 * h->num_edges + 2;
     lg_size = std::max<uint64_t>(lg_size, n + 3);
     lg_size = std::max<uint64_t>(lg_size, (uint64_t)ka * kb + h->num_edges + 2);
+    if (lg_size >= (1ull << 28)) return fail(nullptr, BISBM_ERR_UNSUPPORTED, "graph needs a %llu-entry lgamma table (>= 2^28)", (unsigned long long)lg_size);  // kernels address the tables with 32-bit byte offsets
     const uint32_t kcap = (uint32_t)std::min<uint64_t>(kQNmax, std::max(na, nb) + 1);
     h->tab = get_tables(lg_size, std::max<uint32_t>(kcap, 2));
     h->q_stride = h->tab->kcap + 1;
@@ -572,7 +573,7 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     // LDS plan: m quadrant (odd row stride), m_r, n_r, k_v histogram; eta when it leaves room for
     // four chains per CU; compat adds the two mt19937 states and (small graphs) the visit list
     const size_t K = h->K, D = (size_t)h->maxdeg + 1, S = h->kb | 1u;
-    size_t lds = sizeof(int32_t) * (h->ka * S + 2 * K + std::max(h->ka, h->kb)) + sizeof(uint32_t) * 64 * 64;
+    size_t lds = sizeof(int32_t) * (h->ka * S + 2 * K + std::max<uint32_t>(std::max(h->ka, h->kb), 64)) + sizeof(uint32_t) * 64 * 64;
     const size_t eta_bytes = sizeof(uint32_t) * K * D;
     p.eta_in_lds = (lds + eta_bytes <= 40 * 1024) ? 1 : 0;
     if (p.eta_in_lds) lds += eta_bytes;

@@ -51,7 +51,7 @@ __device__ __forceinline__ void wfence() {
 
 // 8-byte table entry at a 32-bit element index: keeps the address in saddr + voffset form
 __device__ __forceinline__ double tab_at(const double* base, uint32_t idx) {
-    return *(const double*)((const char*)base + ((size_t)idx << 3));
+    return *(const double*)((const char*)base + (uint32_t)(idx << 3));  // tables are < 2^29 entries (host check)
 }
 
 template <bool EL, bool CT>
@@ -64,12 +64,14 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
     const uint32_t D = p.maxdeg + 1, S = kb | 1u;
     // LDS layout, dword offsets
     const uint32_t o_mq = 0, o_mr = ka * S, o_nr = o_mr + K, o_eta = o_nr + K;
-    const uint32_t o_ids = o_eta + (EL ? K * D : 0u);
+    const uint32_t o_hist = o_eta + (EL ? K * D : 0u);
+    const uint32_t o_ids = o_hist + kWave;
     int32_t* const mq = (int32_t*)(lds32 + o_mq);
     int32_t* const mr_l = (int32_t*)(lds32 + o_mr);
     int32_t* const nr_l = (int32_t*)(lds32 + o_nr);
     uint32_t* const eta_l = lds32 + o_eta;
     uint32_t* const ids = lds32 + o_ids;
+    int32_t* const hist = (int32_t*)(lds32 + o_hist);  // k_v of the node being moved, one counter per opposite-type block
 
     uint8_t* const labels = p.labels + (size_t)chain * p.label_stride;
     int32_t* const m_g = p.m + (size_t)chain * ka * kb;
@@ -104,9 +106,6 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
     const double eps = p.epsilon;
     const double Kd = (double)K;
     const double epsK = eps * Kd;
-    uint32_t nbits_a = 0, nbits_b = 0;  // bits of a block index of each type
-    while ((1u << nbits_a) < ka) ++nbits_a;
-    while ((1u << nbits_b) < kb) ++nbits_b;
     const uint32_t chain_gid = p.first_chain_id + chain;
     const uint32_t n = p.n;
     const uint64_t all_sweeps = p.duration / n;
@@ -176,7 +175,6 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
                 const bool type_b = v >= na;
                 const uint32_t k_own = type_b ? kb : ka, k_oth = type_b ? ka : kb;
                 const uint32_t own_base = type_b ? ka : 0u, oth_base = type_b ? 0u : ka;
-                const uint32_t nbits = type_b ? nbits_a : nbits_b;
                 const uint32_t r_loc = r - own_base;
                 const int mr_own = type_b ? mrB : mrA, mr_oth = type_b ? mrA : mrB;
                 const int nr_own = type_b ? nrB : nrA;
@@ -196,31 +194,19 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
                 const int32_t m_rt = lane < k_oth ? mq[a_rt] : 0;
                 const int eta_r = (int)eta_rd(r * D + deg);
 
-                // ---- k_v by ballots: lane t ends with the mask of neighbours whose label is block t ----
+                // ---- k_v: neighbour-label histogram (replaces the dense k_[v] row, blockmodel.cc:691-700):
+                //      LDS counters, three in-order LDS operations, lane t ends with k_t ----
                 const bool act = lane < deg;
-                const uint32_t loc = (uint32_t)(labC - (int)oth_base);
-                unsigned long long mask = __ballot(act);
-#pragma unroll
-                for (uint32_t b = 0; b < 6; ++b) {
-                    if (b < nbits) {
-                        const unsigned long long bb = __ballot(act && ((loc >> b) & 1u));
-                        mask &= (lane >> b) & 1u ? bb : ~bb;
-                    }
-                }
-                int k = lane < k_oth ? (int)__popcll(mask) : 0;
+                hist[lane] = 0;
+                wfence();
+                if (act) atomicAdd(&hist[labC - (int)oth_base], 1);
                 if (deg > (uint32_t)kWave) {  // rows longer than one wave (rare): straight from HBM
                     const uint32_t beg = readlane(beg_l, q);
-                    for (uint32_t j0 = kWave; j0 < deg; j0 += kWave) {
-                        const bool on = j0 + lane < deg;
-                        const uint32_t lc = on ? (uint32_t)labels[p.col[beg + j0 + lane]] - oth_base : 0u;
-                        unsigned long long m2 = __ballot(on);
-                        for (uint32_t b = 0; b < nbits; ++b) {
-                            const unsigned long long bb = __ballot(on && ((lc >> b) & 1u));
-                            m2 &= (lane >> b) & 1u ? bb : ~bb;
-                        }
-                        if (lane < k_oth) k += (int)__popcll(m2);
-                    }
+                    for (uint32_t j = kWave + lane; j < deg; j += kWave)
+                        atomicAdd(&hist[(int)labels[p.col[beg + j]] - (int)oth_base], 1);
                 }
+                wfence();
+                const int k = lane < k_oth ? hist[lane] : 0;
                 FSTAMP(1);
 
                 // ---- proposal: single_vertex_change, blockmodel.cc:613-637 ----
@@ -325,11 +311,7 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
                 if (ok && !same) {
                     wfence();
                     const int ideg = (int)deg;
-                    if (lane == 0) {
-                        nr_l[r] = readlane(nr_own, r_loc) - 1;
-                        nr_l[s] = readlane(nr_own, s_loc) + 1;
-                        mr_l[r] = readlane(mr_own, r_loc) - ideg;
-                        mr_l[s] = readlane(mr_own, s_loc) + ideg;
+                    if (lane == 0) {  // m_r / n_r live in the lane registers; LDS copies are rebuilt at kernel end
                         eta_wr(r * D + deg, (uint32_t)(eta_r - 1));
                         eta_wr(s * D + deg, (uint32_t)(eta_s + 1));
                         labels[v] = (uint8_t)s;
@@ -387,9 +369,13 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
     // chain state -> HBM
     __syncthreads();
     for (uint32_t i = lane; i < ka * kb; i += kWave) m_g[i] = mq[(i / kb) * S + (i % kb)];
-    for (uint32_t i = lane; i < K; i += kWave) {
-        mr_g[i] = mr_l[i];
-        nr_g[i] = nr_l[i];
+    if (lane < ka) {
+        mr_g[lane] = mrA;
+        nr_g[lane] = nrA;
+    }
+    if (lane < kb) {
+        mr_g[ka + lane] = mrB;
+        nr_g[ka + lane] = nrB;
     }
     if (EL)
         for (uint32_t i = lane; i < K * D; i += kWave) eta_g[i] = eta_l[i];
