@@ -189,10 +189,19 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
                 if (nbC == mv_v1) labC = mv_s1;
                 if (nbC == mv_v2) labC = mv_s2;
                 if (nbC == mv_v3) labC = mv_s3;
-                // early LDS reads that only need r
+                // early LDS reads that only need r, and the row of the proposal's pivot block t (it depends on
+                // the uniform and the row only, not on k_v): their latency overlaps the histogram's
                 const uint32_t a_rt = mq_at(r_loc, lane);
                 const int32_t m_rt = lane < k_oth ? mq[a_rt] : 0;
                 const int eta_r = (int)eta_rd(r * D + deg);
+                const double u_idx = readlane(ud_idx, q);
+                uint32_t which = (uint32_t)(u_idx * (double)deg);
+                if (which >= deg) which = deg ? deg - 1 : 0;
+                uint32_t t_piv = oth_base;  // pivot block: label of the which-th neighbour (blockmodel.cc:619-621)
+                if (deg != 0)
+                    t_piv = which < (uint32_t)kWave ? (uint32_t)readlane(labC, which)
+                                                     : (uint32_t)labels[p.col[readlane(beg_l, q) + which]];
+                const int w_piv = lane < k_own ? mq[mq_at(lane, t_piv - oth_base)] : 0;
 
                 // ---- k_v: neighbour-label histogram (replaces the dense k_[v] row, blockmodel.cc:691-700):
                 //      LDS counters, three in-order LDS operations, lane t ends with k_t ----
@@ -210,7 +219,6 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
                 FSTAMP(1);
 
                 // ---- proposal: single_vertex_change, blockmodel.cc:613-637 ----
-                const double u_idx = readlane(ud_idx, q);
                 uint32_t s;
                 if (k_own == 1) {
                     s = r;
@@ -218,12 +226,7 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
                     s = (uint32_t)(u_idx * Kd);
                     if (s >= K) s = K - 1;
                 } else {
-                    uint32_t which = (uint32_t)(u_idx * (double)deg);
-                    if (which >= deg) which = deg - 1;
-                    const uint32_t t = which < (uint32_t)kWave
-                                           ? (uint32_t)readlane(labC, which)
-                                           : (uint32_t)labels[p.col[readlane(beg_l, q) + which]];
-                    const int32_t mrt = readlane(mr_oth, t - oth_base);
+                    const int32_t mrt = readlane(mr_oth, t_piv - oth_base);
                     const double u_tgt = readlane(ud_tgt, q);
                     if (readlane(ud_R, q) * (mrt + epsK) < epsK) {  // u < eps K / (m_r[t] + eps K), :622-624
                         s = (uint32_t)(u_tgt * Kd);
@@ -231,8 +234,7 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
                     } else {  // integer inverse CDF over row m[t][.] restricted to v's own type (:627-628)
                         long long x = (long long)(u_tgt * (double)mrt);
                         if (x >= (long long)mrt) x = (long long)mrt - 1;
-                        const int w = lane < k_own ? mq[mq_at(lane, t - oth_base)] : 0;
-                        const int scan = wave_inclusive_scan(w);
+                        const int scan = wave_inclusive_scan(w_piv);
                         const unsigned long long hit = __ballot(lane < k_own && (long long)scan > x);
                         s = hit ? own_base + (uint32_t)__ffsll((long long)hit) - 1 : own_base + k_own - 1;
                     }
@@ -274,24 +276,26 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
                 const double L4 = tab_at(tab.lg, (uint32_t)(m_st + 1) + kk);
                 FSTAMP(3);
                 gather(q + 3, nbS, labS);  // younger than the gathers above: vmcnt retires in order
-                const double lq = log_q<true>(tab, qn, qk, logn);
-                FSTAMP(4);
-                double a0 = 0., a1 = 0., d = 0.;
+                // the Hastings sums need only on-chip data: they run while the table gathers are in flight
+                double a0 = 0., a1 = 0.;
                 if (k != 0) {
                     const double inv = 1.0 / (mr_oth + epsK);
                     a0 = k * (m_st + eps) * inv;
                     a1 = k * (m_rt - k + eps) * inv;
-                    d = (L1 + L2) - (L3 + L4);
                 }
+                double accu0 = butterfly_sum(a0);
+                double accu1 = butterfly_sum(a1);
+                if (deg == 0) accu0 = accu1 = 1.;
+                FSTAMP(4);
+                const double lq = log_q<true>(tab, qn, qk, logn);
+                FSTAMP(5);
+                double d = 0.;
+                if (k != 0) d = (L1 + L2) - (L3 + L4);
                 // fold the scalar terms into leaves 0..7 / 0..3 with their signs
                 const bool neg_tail = (lane < 2) || (lane >= 6);  // -lg(m0r+1) -lg(m0s+1) ... -lg(eta_r) -lg(eta_s+2)
                 if (lane < 8) d = d + (neg_tail ? -tail_lg : tail_lg);
                 if (lane < 4) d = d + (lane < 2 ? -lq : lq);
-                FSTAMP(5);
                 double dS = butterfly_sum(d);
-                double accu0 = butterfly_sum(a0);
-                double accu1 = butterfly_sum(a1);
-                if (deg == 0) accu0 = accu1 = 1.;
                 FSTAMP(6);
                 // accept (:47-61): T == 0: dS < 0;  else u < exp(-dS/T) accu1/accu0
                 bool accept;
@@ -414,8 +418,8 @@ hipError_t launch_sweep_fast(const SweepParams& p, size_t lds_bytes, hipStream_t
         unsigned long long h[16] = {0};
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fast_stamps), sizeof(h));
         const double steps = (double)p.n_chains * (double)(p.duration / p.n) * (double)p.n;
-        static const char* names[9] = {"loop+consume", "hist", "proposal", "lds+gather issue", "prefetch+log_q",
-                                       "leaf terms", "butterflies", "accept", "apply"};
+        static const char* names[9] = {"loop+consume", "hist", "proposal", "lds+gather issue", "prefetch+accu",
+                                       "log_q", "dS butterfly", "accept", "apply"};
         double tot = 0;
         for (int i = 0; i < 9; ++i) tot += (double)h[i];
         for (int i = 0; i < 9; ++i) fprintf(stderr, "[stamps] %-18s %8.1f cyc/step\n", names[i], (double)h[i] / steps);
