@@ -11,7 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbisbm_hip.so")
 SOURCES = ["bisbm_kernels.hip", "bisbm_sweep_fast.hip", "bisbm_runtime.hip", "bisbm_io.cpp"]
-HEADERS = ["bisbm_device.hpp", "bisbm_kernels.hpp", os.path.join("..", "..", "include", "bisbm.h"),
+HEADERS = ["bisbm_device.hpp", "bisbm_kernels.hpp", os.path.join("..", "host", "bisbm.hpp"),
+           os.path.join("..", "host", "mcmc_main.cpp"), os.path.join("..", "..", "include", "bisbm.h"),
            os.path.join("..", "..", "include", "bisbm_io.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
          "-Wall", "-Wno-unused-function"]
@@ -44,7 +45,24 @@ def build(force=False, verbose=False):
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
     if verbose and r.stderr:
         print(r.stderr, file=sys.stderr)
+    build_cli(verbose=verbose)
     return LIB
+
+
+CLI = os.path.join(HERE, "bin", "mcmc")
+
+
+def build_cli(verbose=False):
+    """The reference's command line (host/mcmc_main.cpp) linked against the in-tree library."""
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    cmd = [hipcc(), "-O2", "-std=c++17", "-o", CLI, os.path.join(HERE, "host", "mcmc_main.cpp"),
+           "-L" + HERE, "-lbisbm_hip", "-Wl,-rpath,$ORIGIN/.."]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building bin/mcmc failed:\n" + r.stdout + r.stderr)
+    return CLI
 
 
 if __name__ == "__main__":

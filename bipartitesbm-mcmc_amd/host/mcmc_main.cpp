@@ -1,0 +1,406 @@
+// mcmc_main.cpp -- the reference's command line (src/mcmc_main.cc) re-hosted on the HIP engine.
+//
+// Same flags (mcmc_main.cc:55-93), same validation messages and exit codes (:99-239), same initial
+// partition rules (:241-326), same stdout contract: the label vector through output_vec (trailing blank,
+// newline), "acceptance ratio" and summary() on clog (:483-485).  Boost.program_options is replaced by a
+// small parser with the same surface (long/short names, `--opt=value`, multitoken options).
+// Extra flags: --chains, --device, --rng {mt19937-compat,philox}, --gen_seed.
+// Not in this build: the agglomerative merge/split drivers (:350-451; SURVEY section 8 "next" f2) -- the
+// flags are parsed and the program says so instead of silently doing something else.
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "bisbm.hpp"
+
+using namespace bisbm_host;
+
+namespace {
+
+struct option_spec {
+    const char* long_name;
+    char short_name;  // 0 = none
+    int kind;         // 0 = flag, 1 = single value, 2 = multitoken
+};
+
+const option_spec kOptions[] = {
+    {"edge_list_path", 'e', 1}, {"membership_path", 0, 1}, {"mb", 0, 2},          {"n", 'n', 2},
+    {"types", 'y', 2},          {"burn_in", 'b', 1},       {"sampling_steps", 't', 1},
+    {"sampling_frequency", 'f', 1}, {"bisbm_partition", 'z', 2}, {"uni", 0, 0},
+    {"cooling_schedule", 'c', 1}, {"cooling_schedule_kwargs", 'a', 2}, {"steps_await", 'x', 1},
+    {"epsilon", 'E', 1},        {"randomize", 'r', 0},     {"merge", 'g', 0},      {"nature", 'u', 0},
+    {"seed", 'd', 1},           {"help", 'h', 0},
+    // engine extras
+    {"chains", 0, 1},           {"device", 0, 1},          {"rng", 0, 1},          {"gen_seed", 0, 1},
+};
+
+const option_spec* find_long(const std::string& name) {
+    for (auto const& o : kOptions)
+        if (name == o.long_name) return &o;
+    return nullptr;
+}
+const option_spec* find_short(char c) {
+    for (auto const& o : kOptions)
+        if (o.short_name && o.short_name == c) return &o;
+    return nullptr;
+}
+bool looks_like_option(const char* s) {
+    if (s[0] != '-' || s[1] == '\0') return false;
+    if (s[1] == '-') return true;
+    return !(s[1] >= '0' && s[1] <= '9') && s[1] != '.';  // "-3" / "-.5" are values
+}
+
+using var_map_t = std::map<std::string, std::vector<std::string>>;
+
+bool parse_command_line(int argc, char const* argv[], var_map_t& vm, std::string& err) {
+    for (int i = 1; i < argc; ++i) {
+        std::string tok = argv[i];
+        const option_spec* spec = nullptr;
+        std::string inline_value;
+        bool has_inline = false;
+        if (tok.rfind("--", 0) == 0) {
+            const size_t eq = tok.find('=');
+            const std::string name = tok.substr(2, eq == std::string::npos ? std::string::npos : eq - 2);
+            spec = find_long(name);
+            if (!spec) {
+                err = "unrecognised option '" + tok + "'";
+                return false;
+            }
+            if (eq != std::string::npos) {
+                inline_value = tok.substr(eq + 1);
+                has_inline = true;
+            }
+        } else if (tok.size() >= 2 && tok[0] == '-') {
+            spec = find_short(tok[1]);
+            if (!spec) {
+                err = "unrecognised option '" + tok + "'";
+                return false;
+            }
+            if (tok.size() > 2) {
+                inline_value = tok.substr(2);
+                has_inline = true;
+            }
+        } else {
+            err = "too many positional options have been specified on the command line";
+            return false;
+        }
+        auto& values = vm[spec->long_name];
+        if (spec->kind == 0) {
+            values.push_back("");
+            continue;
+        }
+        if (has_inline) values.push_back(inline_value);
+        if (spec->kind == 1) {
+            if (!has_inline) {
+                if (i + 1 >= argc) {
+                    err = std::string("the required argument for option '--") + spec->long_name + "' is missing";
+                    return false;
+                }
+                values.push_back(argv[++i]);
+            }
+        } else {
+            while (i + 1 < argc && !looks_like_option(argv[i + 1])) values.push_back(argv[++i]);
+            if (values.empty()) {
+                err = std::string("the required argument for option '--") + spec->long_name + "' is missing";
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
+uint_vec_t to_uints(const std::vector<std::string>& v) {
+    uint_vec_t out;
+    for (auto const& s : v) out.push_back((unsigned)std::strtoul(s.c_str(), nullptr, 10));
+    return out;
+}
+
+void print_help(const char* argv0) {
+    std::clog << "MCMC algorithms for the bipartiteSBM (final output only)\n";
+    std::clog << "Usage:\n  " << argv0 << " [--option_1=value] [--option_s2=value] ...\n";
+    std::clog << "Options:\n"
+                 "  -e [ --edge_list_path ] arg           Path to edge list file.\n"
+                 "  --membership_path arg                 Path to membership file.\n"
+                 "  --mb arg                              Memberships given on the command line.\n"
+                 "  -n [ --n ] arg                        Block sizes vector.\n"
+                 "  -y [ --types ] arg                    Block types vector (NA NB).\n"
+                 "  -b [ --burn_in ] arg (=1000)          Burn-in time (parsed, unused: mcmc_main.cc:61).\n"
+                 "  -t [ --sampling_steps ] arg (=1000)   Length of the annealing process, in MH steps.\n"
+                 "  -f [ --sampling_frequency ] arg (=10) (parsed, unused: mcmc_main.cc:64).\n"
+                 "  -z [ --bisbm_partition ] arg          bipartite number of blocks to be inferred.\n"
+                 "  --uni                                 (parsed, unused).\n"
+                 "  -c [ --cooling_schedule ] arg (=abrupt_cool)\n"
+                 "                                        exponential, linear, logarithmic, constant, abrupt_cool.\n"
+                 "  -a [ --cooling_schedule_kwargs ] arg  Arguments of the cooling schedule (floats).\n"
+                 "  -x [ --steps_await ] arg (=1000)      Stop after x steps without a new minimum.\n"
+                 "  -E [ --epsilon ] arg (=1)             epsilon of the smart proposal.\n"
+                 "  -r [ --randomize ]                    Randomize initial block state.\n"
+                 "  -g [ --merge ]                        Agglomerative merges (not in this build).\n"
+                 "  -u [ --nature ]                       Agglomerative merges, natural start (not in this build).\n"
+                 "  -d [ --seed ] arg                     Seed of the mt19937 engine (clock if absent).\n"
+                 "  -h [ --help ]                         Produce this help message.\n"
+                 "Engine:\n"
+                 "  --chains arg (=1)                     Independent chains; the labels of the chain with the lowest\n"
+                 "                                        description length are printed.\n"
+                 "  --device arg (=0)                     HIP device ordinal.\n"
+                 "  --rng arg (=mt19937-compat)           mt19937-compat (the reference's draw sequence) or philox.\n"
+                 "  --gen_seed arg (=seed+1)              Seed of the reference's hidden second engine (blockmodel.hh:18).\n";
+}
+
+}  // namespace
+
+int main(int argc, char const* argv[]) {
+    var_map_t var_map;
+    std::string err;
+    if (!parse_command_line(argc, argv, var_map, err)) {
+        std::cerr << err << "\n";
+        return 1;
+    }
+    auto count = [&](const char* k) { return var_map.count(k) ? var_map[k].size() : (size_t)0; };
+    auto single = [&](const char* k, const char* dflt) { return count(k) ? var_map[k].back() : std::string(dflt); };
+
+    if (count("help") > 0 || argc == 1) {  // mcmc_main.cc:99-105
+        print_help(argv[0]);
+        return 0;
+    }
+    if (count("edge_list_path") == 0) {
+        std::cerr << "edge_list_path is required (-e flag)\n";
+        return 1;
+    }
+    size_t NA = 0, NB = 0;
+    uint_vec_t types_init;
+    uint_vec_t y = to_uints(var_map["types"]);
+    if (count("types") == 0) {
+        std::cerr << "types is required for bisbm mode (-y flag)\n";
+        return 1;
+    } else if (y.size() != 2) {
+        std::cerr << "Number of types must be equal to 2!\n";
+        return 1;
+    } else {
+        NA = y[0];
+        NB = y[1];
+        types_init.assign(NA + NB, 0);
+        for (size_t i = NA; i < NA + NB; ++i) types_init[i] = 1;
+    }
+    const std::string cooling_schedule = single("cooling_schedule", "abrupt_cool");
+    const size_t sampling_steps = std::strtoull(single("sampling_steps", "1000").c_str(), nullptr, 10);
+    const size_t steps_await = std::strtoull(single("steps_await", "1000").c_str(), nullptr, 10);
+    const double epsilon = std::strtod(single("epsilon", "1").c_str(), nullptr);
+    float_vec_t kwargs(2, 0);
+    if (count("cooling_schedule_kwargs") == 0) {  // defaults, mcmc_main.cc:134-153
+        if (cooling_schedule == "exponential") {
+            kwargs[0] = 1;
+            kwargs[1] = 0.99f;
+        }
+        if (cooling_schedule == "linear") {
+            kwargs[0] = (float)(sampling_steps + 1);
+            kwargs[1] = 1;
+        }
+        if (cooling_schedule == "logarithmic") {
+            kwargs[0] = 1;
+            kwargs[1] = 1;
+        }
+        if (cooling_schedule == "constant") kwargs[0] = 1;
+        if (cooling_schedule == "abrupt_cool") kwargs[0] = (float)steps_await;
+    } else {  // checks, mcmc_main.cc:155-218
+        auto const& a = var_map["cooling_schedule_kwargs"];
+        kwargs.assign(std::max<size_t>(2, a.size()), 0);
+        for (size_t i = 0; i < a.size(); ++i) kwargs[i] = std::strtof(a[i].c_str(), nullptr);
+        if (cooling_schedule == "exponential") {
+            if (kwargs[0] <= 0) {
+                std::cerr << "Invalid cooling schedule argument for linear schedule: T_0 must be grater than 0.\n";
+                std::cerr << "Passed value: T_0=" << kwargs[0] << "\n";
+                return 1;
+            }
+            if (kwargs[1] <= 0 || kwargs[1] >= 1) {
+                std::cerr << "Invalid cooling schedule argument for exponential schedule: alpha must be in ]0,1[.\n";
+                std::cerr << "Passed value: alpha=" << kwargs[1] << "\n";
+                return 1;
+            }
+        } else if (cooling_schedule == "linear") {
+            if (kwargs[0] <= 0) {
+                std::cerr << "Invalid cooling schedule argument for linear schedule: T_0 must be grater than 0.\n";
+                std::cerr << "Passed value: T_0=" << kwargs[0] << "\n";
+                return 1;
+            }
+            if (kwargs[1] <= 0 || kwargs[1] > kwargs[0]) {
+                std::cerr << "Invalid cooling schedule argument for linear schedule: eta must be in ]0, T_0].\n";
+                std::cerr << "Passed value: T_0=" << kwargs[0] << ", eta=" << kwargs[1] << "\n";
+                return 1;
+            }
+            if (kwargs[1] * sampling_steps > kwargs[0]) {
+                std::cerr << "Invalid cooling schedule argument for linear schedule: eta * sampling_steps must be "
+                             "smaller or equal to T_0.\n";
+                std::cerr << "Passed value: eta*sampling_steps=" << kwargs[1] * sampling_steps << ", T_0=" << kwargs[0]
+                          << "\n";
+                return 1;
+            }
+        } else if (cooling_schedule == "logarithmic") {
+            if (kwargs[0] <= 0) {
+                std::cerr << "Invalid cooling schedule argument for logarithmic schedule: c must be greater than 0.\n";
+                std::cerr << "Passed value: c=" << kwargs[0] << "\n";
+                return 1;
+            }
+            if (kwargs[1] <= 0) {
+                std::cerr << "Invalid cooling schedule argument for logarithmic schedule: d must be greater than 0.\n";
+                std::cerr << "Passed value: d=" << kwargs[1] << "\n";
+                return 1;
+            }
+        } else if (cooling_schedule == "constant") {
+            if (kwargs[0] <= 0) {
+                std::cerr << "Invalid cooling schedule argument for constant schedule: temperature must be greater "
+                             "than 0.\n";
+                std::cerr << "Passed value: T=" << kwargs[0] << "\n";
+                return 1;
+            }
+        } else if (cooling_schedule == "abrupt_cool") {
+            if (kwargs[0] <= 0) {
+                std::cerr << "Invalid cooling schedule argument for abrupt_cool schedule: tau must be larger than 0. \n";
+                std::cerr << "Passed value: tau=" << kwargs[0] << "\n";
+                return 1;
+            }
+        } else {
+            std::cerr << "Invalid cooling schedule. Options are exponential, linear, logarithmic, abrupt_cool.\n";
+            return 1;
+        }
+    }
+    // mcmc_main.cc:219-226 tests var_map.count("epsilon"), which is always 1 because of the default value
+    bool randomize = count("randomize") > 0;
+    const bool merge = count("merge") > 0, nature = count("nature") > 0;
+    size_t seed;
+    if (count("seed") == 0)
+        seed = (size_t)std::chrono::high_resolution_clock::now().time_since_epoch().count();  // :236-239
+    else
+        seed = std::strtoull(single("seed", "0").c_str(), nullptr, 10);
+
+    // ---- initial partition, mcmc_main.cc:241-326 ----
+    uint_vec_t memberships_init, n = to_uints(var_map["n"]), z = to_uints(var_map["bisbm_partition"]);
+    uint_vec_t mb = to_uints(var_map["mb"]);
+    size_t N = 0, KA = 0, KB = 0;
+    bool prepared = false;
+    if (count("membership_path") != 0) {
+        std::clog << "Loading nodes' membership from membership_path.\n";
+        if (!load_memberships(memberships_init, single("membership_path", ""))) {
+            std::clog << "WARNING: error in loading memberships, read memberships from block sizes\n";
+        } else {
+            randomize = false;
+            unsigned max_n_ka = 0, max_n_kb = 0;
+            for (size_t i = 0; i < memberships_init.size(); ++i) {
+                if (i < y[0] && memberships_init[i] > max_n_ka) max_n_ka = memberships_init[i];
+                if (memberships_init[i] > max_n_kb) max_n_kb = memberships_init[i];
+            }
+            KA = max_n_ka + 1;
+            KB = max_n_kb - max_n_ka;
+            prepared = true;
+            N = memberships_init.size();
+            std::clog << " ---- read membership from file! ---- \n";
+        }
+    } else if (count("mb") > 0) {
+        size_t accu = 0;
+        for (auto it : n) accu += it;
+        if (mb.size() != accu) {
+            std::cerr << "[error] input vector size of memberships is different from the number of nodes \n";
+            output_vec(mb, std::cerr);
+            std::cerr << "#mb = " << mb.size() << "; while #nodes = " << accu << ". \n";
+            return 1;
+        }
+        memberships_init = mb;
+        if (z.size() < 2) {
+            std::cerr << "number of partitions is required (-z flag)\n";
+            return 1;
+        }
+        KA = z[0];
+        KB = z[1];
+        N = memberships_init.size();
+        prepared = true;
+    }
+    if (!prepared) {
+        if (count("n") == 0) {
+            std::cerr << "n is required (-n flag) if one does not specify the membership of nodes\n";
+            return 1;
+        }
+        for (size_t r = 0; r < n.size(); ++r)
+            for (size_t i = 0; i < n[r]; ++i) memberships_init.push_back((unsigned)r);
+        if (z.size() < 2) {
+            std::cerr << "number of partitions is required (-z flag)\n";
+            return 1;
+        }
+        KA = z[0];
+        KB = z[1];
+        N = memberships_init.size();
+    }
+    if (memberships_init.size() != types_init.size()) {  // :328-333
+        std::cerr << memberships_init.size() << ", " << types_init.size() << '\n';
+        std::cerr << "Types do not sum to the number of vertices!\n";
+        return 1;
+    }
+
+    // ---- graph, mcmc_main.cc:335-339 ----
+    edge_list_t edge_list;
+    load_edge_list(edge_list, single("edge_list_path", ""));
+    const adj_list_t adj_list = edge_to_adj(edge_list, N);
+    edge_list.clear();
+
+    // K implied by the initial labels vs. requested (mcmc_main.cc:406-419)
+    size_t ka = 0, kb = 0;
+    for (size_t t = 0; t < NA + NB; ++t) {
+        if (types_init[t] == 0 && memberships_init[t] > ka)
+            ka = memberships_init[t];
+        else if (types_init[t] == 1 && memberships_init[t] > kb)
+            kb = memberships_init[t];
+    }
+    kb -= ka;
+    ka += 1;
+    if (merge || nature || ka != KA || kb != KB) {
+        std::cerr << "This build runs the fixed-(KA,KB) sweep path (mcmc_main.cc:452-486); the agglomerative merge/split "
+                     "drivers (mcmc_main.cc:350-451) are not part of it yet.\n";
+        return 2;
+    }
+
+    engine_options opt;
+    opt.n_chains = (uint32_t)std::strtoul(single("chains", "1").c_str(), nullptr, 10);
+    opt.device = std::atoi(single("device", "0").c_str());
+    const std::string rng = single("rng", "mt19937-compat");
+    if (rng != "mt19937-compat" && rng != "philox") {
+        std::cerr << "Invalid --rng. Options are mt19937-compat, philox.\n";
+        return 1;
+    }
+    opt.rng_mode = rng == "philox" ? BISBM_RNG_PHILOX : BISBM_RNG_MT19937_COMPAT;
+    opt.seed = seed;
+    opt.gen_seed = count("gen_seed") ? std::strtoull(single("gen_seed", "0").c_str(), nullptr, 10) : seed + 1;
+
+    try {
+        blockmodel_t blockmodel(memberships_init, types_init, KA + KB, KA, KB, epsilon, &adj_list, opt);  // :453
+        if (randomize)
+            blockmodel.shuffle_bisbm();
+        else
+            blockmodel.init_bisbm();
+        metropolis_hasting algorithm;
+        schedule_fn fn = cooling_schedule == "exponential"   ? &exponential_schedule
+                         : cooling_schedule == "linear"      ? &linear_schedule
+                         : cooling_schedule == "logarithmic" ? &logarithmic_schedule
+                         : cooling_schedule == "constant"    ? &constant_schedule
+                                                             : &abrupt_cool_schedule;
+        algorithm.anneal(blockmodel, fn, kwargs, sampling_steps, steps_await);  // :462-482
+        uint32_t best = 0;
+        if (opt.n_chains > 1) {
+            const std::vector<double> dl = blockmodel.entropy_all();
+            for (uint32_t c = 1; c < opt.n_chains; ++c)
+                if (dl[c] < dl[best]) best = c;
+            std::clog << "chains " << opt.n_chains << ", printing chain " << best << "\n";
+        }
+        std::clog << "acceptance ratio " << algorithm.rates()[best] << "\n";  // :483
+        blockmodel.summary(best);                                            // :484
+        output_vec<uint_vec_t>(*blockmodel.get_memberships(best), std::cout);  // :485
+    } catch (const std::exception& e) {
+        std::cerr << e.what() << "\n";
+        return 3;
+    }
+    return 0;
+}

@@ -92,3 +92,34 @@ def test_host_io_matches_oracle(built, tmp_path):
         B.load_edge_list(str(tmp_path / "missing"))
     with pytest.raises(ValueError):
         B.edge_to_adj((np.array([0]), np.array([5])), 3)
+
+
+def test_cli_flag_handling_matches_reference_messages(built):
+    """The re-hosted `mcmc` shell: the reference's validation messages / exit codes (mcmc_main.cc:99-239) are
+    produced before any device is touched."""
+    import subprocess
+    cli = os.path.join(ROOT, "bipartitesbm-mcmc_amd", "bin", "mcmc")
+    if not os.path.exists(cli):
+        B.build(force=True)
+    el = os.path.join(ROOT, "tests", "golden", "southernWomen.edgelist")
+
+    def run(*args):
+        r = subprocess.run([cli, *args], capture_output=True, text=True)
+        return r.returncode, r.stdout, r.stderr
+    rc, out, err = run()
+    assert rc == 0 and "MCMC algorithms for the bipartiteSBM" in err and out == ""
+    assert run("-y", "18", "14") == (1, "", "edge_list_path is required (-e flag)\n")
+    assert run("-e", el) == (1, "", "types is required for bisbm mode (-y flag)\n")
+    assert run("-e", el, "-y", "1", "2", "3") == (1, "", "Number of types must be equal to 2!\n")
+    rc, out, err = run("-e", el, "-y", "18", "14", "-n", "4", "-z", "5", "5", "-c", "exponential", "-a", "10", "1.5")
+    assert rc == 1 and "alpha must be in ]0,1[" in err and "alpha=1.5" in err
+    rc, out, err = run("-e", el, "-y", "18", "14", "-c", "nonsense", "-a", "1")
+    assert rc == 1 and err.startswith("Invalid cooling schedule.")
+    rc, out, err = run("-e", el, "-y", "18", "14", "-z", "5", "5")
+    assert rc == 1 and err == "n is required (-n flag) if one does not specify the membership of nodes\n"
+    rc, out, err = run("-e", el, "-y", "18", "13", "-n", "18", "14", "-z", "1", "1")
+    assert rc == 1 and "Types do not sum to the number of vertices!" in err
+    rc, out, err = run("-e", el, "--bogus")
+    assert rc == 1 and "unrecognised option" in err
+    rc, out, err = run("-e", el, "-y", "18", "14", "-n", "18", "14", "-z", "1", "1", "--merge")
+    assert rc == 2 and "not part of it yet" in err

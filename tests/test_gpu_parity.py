@@ -257,6 +257,22 @@ def test_io_round_trip(tmp_path):
     assert B.output_vec([3, 0, 12], stream=open(os.devnull, "w")) == "3 0 12 \n"
 
 
+def test_cli_golden(golden):
+    """The re-hosted `mcmc` command line prints the reference's recorded labels for config 1
+    (engine seed 42, gen seed 43): stdout is the label line of output_vec, byte for byte."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "bipartitesbm-mcmc_amd", "bin", "mcmc")
+    g = golden["compat_rng"]["scenario1_config1"]
+    r = subprocess.run([cli, "-e", os.path.join(O.GOLDEN, "southernWomen.edgelist"), "-n", "4", "4", "3", "4", "3", "3",
+                        "3", "3", "3", "2", "-y", "18", "14", "-z", "5", "5", "-t", "32000", "-x", "100", "-c",
+                        "exponential", "-a", "10", "0.1", "-E", "0.001", "--randomize", "-d", "42", "--gen_seed", "43"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == " ".join(map(str, g["labels"])) + " \n"
+    assert "acceptance ratio 0.248264" in r.stderr and "(Ka, Kb) = (5, 5) " in r.stderr and "entropy: 221.095" in r.stderr
+
+
 # ------------------------------------------------------------------ full size: properties
 def test_full_size_properties():
     """BASELINE config 3 graph (N_a=N_b=5e5, E=1e7, Ka=Kb=32) with a handful of chains: one sweep keeps
