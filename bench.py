@@ -147,6 +147,15 @@ def main():
         balg = b_alg_per_update(n, E)
         achieved = balg * per_launch_updates / avg_kernel_s / 1e9
         default_cfg = (na, nb, E, ka, kb, args.chains) == (500_000, 500_000, 10_000_000, 32, 32, 1024)
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
+        # WRITE_SIZE, separate runs of this same command); only quoted for the workload they were measured on
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if default_cfg and os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            traffic = tj["bytes_per_update"] * per_launch_updates
+            traffic_src = "profiles/r01_traffic.json (FETCH_SIZE+WRITE_SIZE, %.0f B per update)" % tj["bytes_per_update"]
         out = {
             "metric": "node-label MH updates/s",
             "value": total_updates / elapsed,
@@ -169,8 +178,8 @@ def main():
                 "parallelism": "chains sharded, no collective in the sweep path",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "sweep_kernel<philox>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "bound": "hbm", "kernel": "sweep_fast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "alg_bytes_per_update": balg, "updates_per_launch": per_launch_updates,
                 "avg_launch_ms": avg_kernel_s * 1e3,
             },
