@@ -83,10 +83,18 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; BISBM_BENCH_BACKEND=gloo lets the multi-rank path be rehearsed on a one-GPU box
+    # (several ranks then share device 0 and the collectives run on CPU tensors)
+    backend = os.environ.get("BISBM_BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    coll_device = torch.device("cuda", device_index) if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     pkg = importlib.import_module("bipartitesbm-mcmc_amd")
     syn = importlib.import_module("bipartitesbm-mcmc_amd.synthetic")
@@ -101,7 +109,7 @@ def main():
     labels = syn.contiguous_labels(na, nb, ka, kb)
     shard = pkg.ChainShard(args.chains * world, rank=rank, world_size=world)
     model = pkg.BlockModel(labels, syn.types_vector(na, nb), ka + kb, ka, kb, 1.0, (rowptr, col),
-                           n_chains=shard.n_local, rng="philox", seed=20240229, device=local_rank,
+                           n_chains=shard.n_local, rng="philox", seed=20240229, device=device_index,
                            first_chain_id=shard.first_chain_id)
     model.shuffle_bisbm()  # --randomize start
     mh = pkg.MetropolisHasting()
@@ -124,17 +132,17 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        u = torch.tensor([updates], dtype=torch.int64, device="cuda")
+        u = torch.tensor([updates], dtype=torch.int64, device=coll_device)
         dist.all_reduce(u, op=dist.ReduceOp.SUM)
         total_updates = int(u.item())
     else:
         total_updates = updates
 
     # pooling epilogue (outside the timed region): RCCL all_gather of the per-chain sums
-    cum = torch.from_numpy(model.get_entropy()).to("cuda").reshape(-1, 1)
+    cum = torch.from_numpy(model.get_entropy()).to(coll_device).reshape(-1, 1)
     t1 = time.perf_counter()
     allcum = shard.all_gather_chain_values(cum)
     torch.cuda.synchronize()

@@ -80,6 +80,27 @@ __device__ __forceinline__ double butterfly_sum(double x) {
     return readlane(x, 63u);
 }
 
+// Two butterfly sums at once when both inputs are zero in lanes 32..63 (at most 32 leaves in use): b is
+// moved to the upper half with v_permlane32_swap and one 32-leaf butterfly per half gives both sums.
+// Same tree as butterfly_sum: its last level would only add the empty upper half (x + 0.0 = x).
+__device__ __forceinline__ void butterfly_pair32(double a, double b, double& sum_a, double& sum_b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    double x = __hiloint2double(hi[0], lo[0]);  // lanes 0..31: a, lanes 32..63: b's lanes 0..31
+    x = x + dpp_f64<kDppXor1>(x);
+    x = x + dpp_f64<kDppXor2>(x);
+    x = x + dpp_f64<kDppHalfMirror>(x);
+    x = x + dpp_f64<kDppMirror>(x);
+    {
+        const int l = __builtin_amdgcn_update_dpp(0, __double2loint(x), kDppBcast15, 0xA, 0xF, false);
+        const int h = __builtin_amdgcn_update_dpp(0, __double2hiint(x), kDppBcast15, 0xA, 0xF, false);
+        const double y = __hiloint2double(h, l);
+        x = ((lane_id() >> 4) & 1) ? x + y : x;
+    }
+    sum_a = readlane(x, 31u);
+    sum_b = readlane(x, 63u);
+}
+
 // inclusive prefix sum of int32 over the wave: Kogge-Stone inside rows (row_shr), then the row
 // totals are carried with row_bcast15 / row_bcast31
 __device__ __forceinline__ int wave_inclusive_scan(int x) {

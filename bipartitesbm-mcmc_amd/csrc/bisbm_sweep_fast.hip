@@ -51,6 +51,9 @@ __device__ __forceinline__ void wfence() {
 
 // 8-byte table entry at a 32-bit element index: keeps the address in saddr + voffset form
 __device__ __forceinline__ double tab_at(const double* base, uint32_t idx) {
+#if defined(BISBM_ABLATE) && (BISBM_ABLATE & 8)
+    return (double)idx * 1e-3 + (double)((size_t)base & 0xff);  // diagnostic build: table gathers removed (wrong results)
+#endif
     return *(const double*)((const char*)base + (uint32_t)(idx << 3));  // tables are < 2^29 entries (host check)
 }
 
@@ -150,26 +153,57 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
             __builtin_amdgcn_s_waitcnt(0);  // the DMA writes have landed before any ds_read of ids
             wfence();
 
-            // label pipeline (depth 3).  The label load is unconditional (idle lanes read node 0).
-            auto gather = [&](uint32_t qq, uint32_t& nb, int& lab) {
+            // label pipeline (depth 3).  The label load is unconditional (idle lanes read node 0); the ids of
+            // the stage to refill are read from LDS at the start of a step so that the load itself never
+            // waits on LDS.
+            auto stage_ids = [&](uint32_t qq) -> uint32_t {  // neighbour id of lane, 0xFFFFFFFF when idle
+                uint32_t nb = 0xFFFFFFFFu;
                 if (qq < cnt) {
-                    const uint32_t d = readlane(deg_l, qq);
                     const uint32_t id = ids[qq * kWave + lane];
-                    const bool on = lane < d;
-                    nb = on ? id : 0xFFFFFFFFu;
-                    lab = labels[on ? id : 0u];
+                    nb = lane < readlane(deg_l, qq) ? id : 0xFFFFFFFFu;
                 }
+                return nb;
             };
-            uint32_t nb1 = 0xFFFFFFFFu, nb2 = 0xFFFFFFFFu, nb3 = 0xFFFFFFFFu;
+            auto stage_load = [&](uint32_t qq, uint32_t nb, int& lab) {
+#if defined(BISBM_ABLATE) && (BISBM_ABLATE & 16)
+                if (qq < cnt) lab = labels[nb == 0xFFFFFFFFu ? 0u : ((nb & 1023u) + (nb >= na ? na : 0u))];  // diagnostic: cache-resident labels
+#elif defined(BISBM_ABLATE) && (BISBM_ABLATE & 32)
+                if (qq < cnt) lab = (int)((nb == 0xFFFFFFFFu ? 0u : nb) >= na ? ka + (nb & 31u) : (nb & 31u));  // diagnostic: no label loads at all
+#else
+                if (qq < cnt) lab = labels[nb == 0xFFFFFFFFu ? 0u : nb];
+#endif
+            };
+            uint32_t nb1 = stage_ids(0), nb2 = stage_ids(1), nb3 = stage_ids(2);
             int lab1 = 0, lab2 = 0, lab3 = 0;
-            gather(0, nb1, lab1);
-            gather(1, nb2, lab2);
-            gather(2, nb3, lab3);
+            stage_load(0, nb1, lab1);
+            stage_load(1, nb2, lab2);
+            stage_load(2, nb3, lab3);
             const uint32_t kNoMove = 0xFFFFFFFEu;
             uint32_t mv_v1 = kNoMove, mv_v2 = kNoMove, mv_v3 = kNoMove;  // moves of steps q-3, q-2, q-1
             int mv_s1 = 0, mv_s2 = 0, mv_s3 = 0;
+            // k_v of a step is accumulated in LDS: zero the counters, add one per neighbour label (labels patched with every move
+            // made so far), for rows longer than a wave the remainder straight from HBM.
+            auto hist_build = [&](uint32_t qq, uint32_t nbX, int labX) {
+                if (qq < cnt) {
+                    const uint32_t vq = readlane(v_l, qq), dq = readlane(deg_l, qq);
+                    const uint32_t ob = vq >= na ? 0u : ka;  // base of the opposite type's block ids
+                    int lab = labX;
+                    if (nbX == mv_v1) lab = mv_s1;
+                    if (nbX == mv_v2) lab = mv_s2;
+                    if (nbX == mv_v3) lab = mv_s3;
+                    hist[lane] = 0;
+                    wfence();
+                    if (lane < dq) atomicAdd(&hist[lab - (int)ob], 1);
+                    if (dq > (uint32_t)kWave) {
+                        const uint32_t beg = readlane(beg_l, qq);
+                        for (uint32_t j = kWave + lane; j < dq; j += kWave)
+                            atomicAdd(&hist[(int)labels[p.col[beg + j]] - (int)ob], 1);
+                    }
+                    wfence();
+                }
+            };
 
-            auto do_step = [&](const uint32_t q, uint32_t& nbS, int& labS) {
+            auto do_step = [&](const uint32_t q, uint32_t& nbS, int& labS, const uint32_t& nbNext, const int& labNext) {
                 FSTAMP(0);
                 const uint32_t v = readlane(v_l, q), deg = readlane(deg_l, q), r = readlane(r_l, q);
                 const bool type_b = v >= na;
@@ -203,19 +237,10 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
                                                      : (uint32_t)labels[p.col[readlane(beg_l, q) + which]];
                 const int w_piv = lane < k_own ? mq[mq_at(lane, t_piv - oth_base)] : 0;
 
-                // ---- k_v: neighbour-label histogram (replaces the dense k_[v] row, blockmodel.cc:691-700):
-                //      LDS counters, three in-order LDS operations, lane t ends with k_t ----
-                const bool act = lane < deg;
-                hist[lane] = 0;
-                wfence();
-                if (act) atomicAdd(&hist[labC - (int)oth_base], 1);
-                if (deg > (uint32_t)kWave) {  // rows longer than one wave (rare): straight from HBM
-                    const uint32_t beg = readlane(beg_l, q);
-                    for (uint32_t j = kWave + lane; j < deg; j += kWave)
-                        atomicAdd(&hist[(int)labels[p.col[beg + j]] - (int)oth_base], 1);
-                }
-                wfence();
+                // ---- k_v (replaces the dense k_[v] row, blockmodel.cc:691-700): LDS counters ----
+                hist_build(q, nbS, labS);
                 const int k = lane < k_oth ? hist[lane] : 0;
+                const uint32_t nbN = stage_ids(q + 3);  // ids of the stage this step will refill
                 FSTAMP(1);
 
                 // ---- proposal: single_vertex_change, blockmodel.cc:613-637 ----
@@ -275,7 +300,8 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
                 const double L3 = tab_at(tab.lg, (uint32_t)(m_rt + 1) - kk);
                 const double L4 = tab_at(tab.lg, (uint32_t)(m_st + 1) + kk);
                 FSTAMP(3);
-                gather(q + 3, nbS, labS);  // younger than the gathers above: vmcnt retires in order
+                nbS = nbN;
+                stage_load(q + 3, nbN, labS);  // younger than the gathers above: vmcnt retires in order
                 // the Hastings sums need only on-chip data: they run while the table gathers are in flight
                 double a0 = 0., a1 = 0.;
                 if (k != 0) {
@@ -283,8 +309,13 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
                     a0 = k * (m_st + eps) * inv;
                     a1 = k * (m_rt - k + eps) * inv;
                 }
-                double accu0 = butterfly_sum(a0);
-                double accu1 = butterfly_sum(a1);
+                double accu0, accu1;
+                if (k_oth <= 32u) {
+                    butterfly_pair32(a0, a1, accu0, accu1);
+                } else {
+                    accu0 = butterfly_sum(a0);
+                    accu1 = butterfly_sum(a1);
+                }
                 if (deg == 0) accu0 = accu1 = 1.;
                 FSTAMP(4);
                 const double lq = log_q<true>(tab, qn, qk, logn);
@@ -355,9 +386,9 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
                 }
             };
             for (uint32_t q = 0; q < cnt; q += 3) {
-                do_step(q, nb1, lab1);
-                if (q + 1 < cnt) do_step(q + 1, nb2, lab2);
-                if (q + 2 < cnt) do_step(q + 2, nb3, lab3);
+                do_step(q, nb1, lab1, nb2, lab2);
+                if (q + 1 < cnt) do_step(q + 1, nb2, lab2, nb3, lab3);
+                if (q + 2 < cnt) do_step(q + 2, nb3, lab3, nb1, lab1);
             }
         }
         ++sweeps_total;
