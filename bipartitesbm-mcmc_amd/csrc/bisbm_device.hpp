@@ -391,13 +391,13 @@ template <bool FAST>
 __device__ inline double log_q_approx(const Tables& t, unsigned long long n, unsigned long long k, double logn_pre) {
     const double kPi = 3.14159265358979323846;
     const bool small = k < 65536ull && (k * k) * (k * k) < n;  // int_part.cc:90
-    if (small) return lbinom_fast(t, n - 1, k - 1) - lgamma_fast(t, (long long)(k + 1));  // :73-75
+    if (__builtin_expect(small, 0)) return lbinom_fast(t, n - 1, k - 1) - lgamma_fast(t, (long long)(k + 1));  // :73-75
     const double sq = sqrt((double)n);
     const double u = (double)k / sq;  // :92
     const double C0 = 0x1.48552f88091a8p+0;    // pi / sqrt(6)
     const double C1 = 0x1.37423899a1558p-2;    // 3 / pi^2
     const double LFC = -0x1.ef8383c50bb74p+0;  // log(pi/sqrt 6) - 1.5 log 2 - log pi
-    if (FAST && u > 24.0) {
+    if (FAST && __builtin_expect(u > 24.0, 1)) {
         // For u > 24 the iteration's limit can be written down directly: v = C0 u (1 - eps) with
         // eps = C1 (C0 u + 1) x, x = exp(-C0 u) (the first iterate's own correction changes x by
         // < 1e-8 relative, i.e. the result by < 1e-17).  log(n) comes from the host-built table.
@@ -433,7 +433,7 @@ template <bool FAST>
 __device__ inline double log_q(const Tables& t, int n, int k, double logn_pre = 0.) {  // int_part.hh:27-37
     if (n <= 0 || k < 1) return 0;
     if (k > n) k = n;
-    if (n < kQNmax + 1) {
+    if (__builtin_expect(n < kQNmax + 1, 0)) {
         if ((uint32_t)k >= t.q_stride) return NAN;  // outside the uploaded columns (cannot happen on the sweep path)
         return t.q[(size_t)n * t.q_stride + (size_t)k];
     }

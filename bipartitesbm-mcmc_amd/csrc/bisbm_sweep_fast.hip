@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
                     hist[lane] = 0;
                     wfence();
                     if (lane < dq) atomicAdd(&hist[lab - (int)ob], 1);
-                    if (dq > (uint32_t)kWave) {
+                    if (__builtin_expect(dq > (uint32_t)kWave, 0)) {
                         const uint32_t beg = readlane(beg_l, qq);
                         for (uint32_t j = kWave + lane; j < dq; j += kWave)
                             atomicAdd(&hist[(int)labels[p.col[beg + j]] - (int)ob], 1);
@@ -245,15 +245,15 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
 
                 // ---- proposal: single_vertex_change, blockmodel.cc:613-637 ----
                 uint32_t s;
-                if (k_own == 1) {
+                if (__builtin_expect(k_own == 1, 0)) {
                     s = r;
-                } else if (deg == 0) {
+                } else if (__builtin_expect(deg == 0, 0)) {
                     s = (uint32_t)(u_idx * Kd);
                     if (s >= K) s = K - 1;
                 } else {
                     const int32_t mrt = readlane(mr_oth, t_piv - oth_base);
                     const double u_tgt = readlane(ud_tgt, q);
-                    if (readlane(ud_R, q) * (mrt + epsK) < epsK) {  // u < eps K / (m_r[t] + eps K), :622-624
+                    if (__builtin_expect(readlane(ud_R, q) * (mrt + epsK) < epsK, 0)) {  // u < eps K / (m_r[t] + eps K), :622-624
                         s = (uint32_t)(u_tgt * Kd);
                         if (s >= K) s = K - 1;
                     } else {  // integer inverse CDF over row m[t][.] restricted to v's own type (:627-628)
@@ -283,15 +283,17 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
                 const int m0r = readlane(mr_own, r_loc);
                 const int m0s = readlane(mr_own, s_loc);
                 const int n_r_r = readlane(nr_own, r_loc), n_r_s = readlane(nr_own, s_loc);
-                // lanes 0..7: the scalar lgamma terms (:164-177); lanes 0..3 also carry the log_q arguments
+                // lanes 0..7: the scalar lgamma terms (:164-177); lanes 0..3 also carry the log_q arguments.  The
+                // pattern repeats every 8 / 4 lanes so that every lane runs the same control flow (no exec
+                // juggling, no skipped-region branches); only lanes 0..7 / 0..3 are used.
                 const bool odd = lane & 1u;
-                const int mm = odd ? m0s : m0r;                         // lanes 0,1: m0r, m0s
-                const int dd = (lane & 2u) ? (odd ? ideg : -ideg) : 0;  // lanes 2,3: m1r, m1s
+                const int mm = odd ? m0s : m0r;                         // m0r, m0s
+                const int dd = (lane & 2u) ? (odd ? ideg : -ideg) : 0;  // -> m1r, m1s in lanes 2,3 (mod 4)
                 const int ee = odd ? eta_s : eta_r;
-                const int eoff = lane < 6 ? 1 : (odd ? 2 : 0);  // eta_r+1, eta_s+1, eta_r, eta_s+2
-                const uint32_t tail_idx = lane < 4 ? (uint32_t)(mm + dd + 1) : (lane < 8 ? (uint32_t)(ee + eoff) : 1u);
-                const int qn = lane < 4 ? mm + dd : 0;
-                const int qk = lane < 4 ? (odd ? n_r_s : n_r_r) + ((lane & 2u) ? (odd ? 1 : -1) : 0) : 0;
+                const int eoff = (lane & 7u) < 6 ? 1 : (odd ? 2 : 0);  // eta_r+1, eta_s+1, eta_r, eta_s+2
+                const uint32_t tail_idx = (lane & 4u) ? (uint32_t)(ee + eoff) : (uint32_t)(mm + dd + 1);
+                const int qn = mm + dd;
+                const int qk = (odd ? n_r_s : n_r_r) + ((lane & 2u) ? (odd ? 1 : -1) : 0);
                 const double tail_lg = tab_at(tab.lg, tail_idx);
                 const double logn = tab_at(tab.logtab, (uint32_t)qn);  // log(n) of the four log_q arguments
                 const uint32_t kk = (uint32_t)k;
@@ -303,12 +305,10 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
                 nbS = nbN;
                 stage_load(q + 3, nbN, labS);  // younger than the gathers above: vmcnt retires in order
                 // the Hastings sums need only on-chip data: they run while the table gathers are in flight
-                double a0 = 0., a1 = 0.;
-                if (k != 0) {
-                    const double inv = 1.0 / (mr_oth + epsK);
-                    a0 = k * (m_st + eps) * inv;
-                    a1 = k * (m_rt - k + eps) * inv;
-                }
+                // k == 0 lanes give exact zeros (0 * x = +0, identical table entries cancel): no branch needed
+                const double inv = 1.0 / (mr_oth + epsK);
+                const double a0 = k * (m_st + eps) * inv;
+                const double a1 = k * (m_rt - k + eps) * inv;
                 double accu0, accu1;
                 if (k_oth <= 32u) {
                     butterfly_pair32(a0, a1, accu0, accu1);
@@ -320,17 +320,16 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
                 FSTAMP(4);
                 const double lq = log_q<true>(tab, qn, qk, logn);
                 FSTAMP(5);
-                double d = 0.;
-                if (k != 0) d = (L1 + L2) - (L3 + L4);
+                double d = (L1 + L2) - (L3 + L4);
                 // fold the scalar terms into leaves 0..7 / 0..3 with their signs
                 const bool neg_tail = (lane < 2) || (lane >= 6);  // -lg(m0r+1) -lg(m0s+1) ... -lg(eta_r) -lg(eta_s+2)
-                if (lane < 8) d = d + (neg_tail ? -tail_lg : tail_lg);
-                if (lane < 4) d = d + (lane < 2 ? -lq : lq);
+                d = lane < 8 ? d + (neg_tail ? -tail_lg : tail_lg) : d;
+                d = lane < 4 ? d + (lane < 2 ? -lq : lq) : d;
                 double dS = butterfly_sum(d);
                 FSTAMP(6);
                 // accept (:47-61): T == 0: dS < 0;  else u < exp(-dS/T) accu1/accu0
                 bool accept;
-                if (T == 0.)
+                if (__builtin_expect(T == 0., 0))
                     accept = dS < 0;
                 else
                     accept = readlane(ud_acc, q) * accu0 < accu1 * exp(-dS * (1.0 / T));
@@ -387,8 +386,8 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
             };
             for (uint32_t q = 0; q < cnt; q += 3) {
                 do_step(q, nb1, lab1, nb2, lab2);
-                if (q + 1 < cnt) do_step(q + 1, nb2, lab2, nb3, lab3);
-                if (q + 2 < cnt) do_step(q + 2, nb3, lab3, nb1, lab1);
+                if (__builtin_expect(q + 1 < cnt, 1)) do_step(q + 1, nb2, lab2, nb3, lab3);
+                if (__builtin_expect(q + 2 < cnt, 1)) do_step(q + 2, nb3, lab3, nb1, lab1);
             }
         }
         ++sweeps_total;
