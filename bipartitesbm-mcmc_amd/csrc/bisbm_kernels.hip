@@ -481,11 +481,12 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
     double rate = 0.;
     bool stopped = false;
     for (uint64_t sweep = 0; sweep < all_sweeps; ++sweep) {
-        Feistel order;
+        Feistel order_a, order_b;  // Philox mode: all type-a nodes, then all type-b nodes, each class permuted
         if (RNG == RNG_COMPAT) {
             mt_shuffle(engine, vl, (uint32_t)num_nodes);  // :80
         } else {
-            order.init(phx_draw(p.seed, chain_gid, PHX_SWEEP_KEY, sweeps_total), (uint32_t)num_nodes);
+            order_a.init(phx_draw(p.seed, chain_gid, PHX_SWEEP_KEY, 2 * sweeps_total), p.na);
+            order_b.init(phx_draw(p.seed, chain_gid, PHX_SWEEP_KEY, 2 * sweeps_total + 1), p.nb);
         }
         const uint64_t current_step = num_nodes * sweep;  // :82
         for (uint64_t vi0 = 0; vi0 < num_nodes; vi0 += kWave) {
@@ -495,7 +496,8 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
             const uint32_t cnt = (num_nodes - vi0) < (uint64_t)kWave ? (uint32_t)(num_nodes - vi0) : (uint32_t)kWave;
             uint32_t v_l = 0, beg_l = 0, deg_l = 0, r_l = 0;
             if ((uint32_t)lane < cnt) {
-                v_l = (RNG == RNG_COMPAT) ? vl[vi0 + lane] : order((uint32_t)(vi0 + lane));
+                const uint32_t pos = (uint32_t)(vi0 + lane);
+                v_l = (RNG == RNG_COMPAT) ? vl[pos] : (pos < p.na ? order_a(pos) : p.na + order_b(pos - p.na));
                 beg_l = p.rowptr[v_l];
                 deg_l = p.rowptr[v_l + 1] - beg_l;
                 r_l = c.labels[v_l];

@@ -126,6 +126,7 @@ __device__ __forceinline__ double temperature_of(const SweepParams& p, uint64_t 
 
 hipError_t launch_sweep(const SweepParams& p, int rng_mode, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_sweep_fast(const SweepParams& p, size_t lds_bytes, hipStream_t stream);
+size_t sweep_fast_lds_bytes(uint32_t ka, uint32_t kb, uint32_t maxdeg, bool eta_in_lds);
 hipError_t launch_state_build(const BuildParams& p, hipStream_t stream);
 hipError_t launch_labels_broadcast(const uint32_t* src, uint8_t* labels, size_t label_stride, uint32_t n,
                                    uint32_t first_chain, uint32_t n_chains, hipStream_t stream);

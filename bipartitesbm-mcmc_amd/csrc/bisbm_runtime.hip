@@ -570,29 +570,37 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
         p.T_zero_after = zero_after;
     }
 
-    // LDS plan: m quadrant (odd row stride), m_r, n_r, k_v histogram; eta when it leaves room for
-    // four chains per CU; compat adds the two mt19937 states and (small graphs) the visit list
-    const size_t K = h->K, D = (size_t)h->maxdeg + 1, S = h->kb | 1u;
-    size_t lds = sizeof(int32_t) * (h->ka * S + 2 * K + std::max<uint32_t>(std::max(h->ka, h->kb), 64)) + sizeof(uint32_t) * 64 * 64;
-    const size_t eta_bytes = sizeof(uint32_t) * K * D;
-    p.eta_in_lds = (lds + eta_bytes <= 40 * 1024) ? 1 : 0;
-    if (p.eta_in_lds) lds += eta_bytes;
-    p.vlist_in_lds = 0;
-    if (h->rng_mode == BISBM_RNG_MT19937_COMPAT) {
-        lds += sizeof(uint32_t) * 624 * 2;
-        if (sizeof(uint32_t) * h->n <= 48 * 1024) {
-            p.vlist_in_lds = 1;
-            lds += sizeof(uint32_t) * h->n;
-        }
-    }
-    lds = (lds + 15) & ~(size_t)15;
-    if (lds > 160 * 1024) return fail(h, BISBM_ERR_UNSUPPORTED, "chain state needs %zu B of LDS (> 160 KiB)", lds);
-
-    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     // the production kernel covers Philox mode with both block counts <= 64; mt19937-compat mode and
     // wider partitions run the generic kernel (BISBM_FORCE_GENERIC=1 forces it, for A/B checks)
     const char* force = getenv("BISBM_FORCE_GENERIC");
     const bool fast = h->rng_mode == BISBM_RNG_PHILOX && h->ka <= 64 && h->kb <= 64 && !(force && force[0] == '1');
+    // LDS plan.  eta goes to LDS when that still leaves room for four chains per CU (160 KiB / 4).
+    const size_t K = h->K, D = (size_t)h->maxdeg + 1, S = h->kb | 1u;
+    const size_t eta_bytes = sizeof(uint32_t) * K * D;
+    size_t lds;
+    p.vlist_in_lds = 0;
+    if (fast) {
+        lds = sweep_fast_lds_bytes(h->ka, h->kb, h->maxdeg, false);
+        p.eta_in_lds = (lds + eta_bytes <= 40 * 1024) ? 1 : 0;
+        lds = sweep_fast_lds_bytes(h->ka, h->kb, h->maxdeg, p.eta_in_lds != 0);
+    } else {
+        // generic kernel: m quadrant (odd row stride), m_r, n_r, k_v histogram, staged rows; compat adds the
+        // two mt19937 states and (small graphs) the visit list
+        lds = sizeof(int32_t) * (h->ka * S + 2 * K + std::max<uint32_t>(std::max(h->ka, h->kb), 64)) + sizeof(uint32_t) * 64 * 64;
+        p.eta_in_lds = (lds + eta_bytes <= 40 * 1024) ? 1 : 0;
+        if (p.eta_in_lds) lds += eta_bytes;
+        if (h->rng_mode == BISBM_RNG_MT19937_COMPAT) {
+            lds += sizeof(uint32_t) * 624 * 2;
+            if (sizeof(uint32_t) * h->n <= 48 * 1024) {
+                p.vlist_in_lds = 1;
+                lds += sizeof(uint32_t) * h->n;
+            }
+        }
+        lds = (lds + 15) & ~(size_t)15;
+    }
+    if (lds > 160 * 1024) return fail(h, BISBM_ERR_UNSUPPORTED, "chain state needs %zu B of LDS (> 160 KiB)", lds);
+
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     if (fast)
         HIPCHK(h, launch_sweep_fast(p, lds, h->stream));
     else

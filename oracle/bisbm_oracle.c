@@ -402,10 +402,18 @@ static uint32_t feistel_perm(const uint32_t keys[4], uint32_t n, uint32_t i) {
     return x;
 }
 
-uint32_t orc_philox_visit(uint64_t seed, uint32_t chain, uint64_t sweep, uint32_t n, uint32_t i) {
+/* Philox-mode visit order of one sweep: first every type-a node, then every type-b node (the two colour
+ * classes of the bipartite graph: within a phase no visited node is a neighbour of another, so the
+ * neighbour labels a step reads are frozen for the whole phase), each class in its own keyed
+ * permutation.  Position i in [0, na+nb). */
+uint32_t orc_philox_visit(uint64_t seed, uint32_t chain, uint64_t sweep, uint32_t na, uint32_t nb, uint32_t i) {
     uint32_t keys[4];
-    phx_draw(seed, chain, PHX_SWEEP_KEY, sweep, keys);
-    return feistel_perm(keys, n, i);
+    if (i < na) {
+        phx_draw(seed, chain, PHX_SWEEP_KEY, 2 * sweep, keys);
+        return feistel_perm(keys, na, i);
+    }
+    phx_draw(seed, chain, PHX_SWEEP_KEY, 2 * sweep + 1, keys);
+    return na + feistel_perm(keys, nb, i - na);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1044,11 +1052,13 @@ double orc_anneal(orc_model *m, int schedule, float kw0, float kw1, uint64_t dur
     double temperature = 1;
     m->last_sweeps = 0;
     for (uint64_t sweep = 0; sweep < all_sweeps; ++sweep) {
-        uint32_t keys[4];
+        uint32_t keys_a[4], keys_b[4];
         if (m->rng_mode == ORC_RNG_COMPAT)
             orc_mt_shuffle_u32(&m->engine, m->vlist, num_nodes);
-        else
-            phx_draw(m->phx_seed, m->phx_chain, PHX_SWEEP_KEY, m->sweeps_total, keys);
+        else {
+            phx_draw(m->phx_seed, m->phx_chain, PHX_SWEEP_KEY, 2 * m->sweeps_total, keys_a);
+            phx_draw(m->phx_seed, m->phx_chain, PHX_SWEEP_KEY, 2 * m->sweeps_total + 1, keys_b);
+        }
         uint64_t current_step = num_nodes * sweep;
         for (size_t vi = 0; vi < num_nodes; ++vi) {
             temperature = orc_schedule(schedule, current_step + vi, kw0, kw1);
@@ -1056,7 +1066,8 @@ double orc_anneal(orc_model *m, int schedule, float kw0, float kw1, uint64_t dur
             if (m->rng_mode == ORC_RNG_COMPAT)
                 ok = step_compat(m, m->vlist[vi], temperature);
             else {
-                size_t v = feistel_perm(keys, (uint32_t)num_nodes, (uint32_t)vi);
+                size_t v = vi < m->na ? feistel_perm(keys_a, (uint32_t)m->na, (uint32_t)vi)
+                                      : m->na + feistel_perm(keys_b, (uint32_t)m->nb, (uint32_t)(vi - m->na));
                 ok = step_philox(m, v, temperature, m->sweeps_total * num_nodes + vi);
             }
             if (ok) {

@@ -80,7 +80,7 @@ size_t orc_mt_discrete(orc_mt19937 *g, const int *w, size_t n);
 /* ---- Philox4x32-10 (production RNG; Salmon et al. SC'11) ---- */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 /* sweep visit order in Philox mode: position i of sweep `sweep` of chain `chain` */
-uint32_t orc_philox_visit(uint64_t seed, uint32_t chain, uint64_t sweep, uint32_t n, uint32_t i);
+uint32_t orc_philox_visit(uint64_t seed, uint32_t chain, uint64_t sweep, uint32_t na, uint32_t nb, uint32_t i);
 
 /* ---- model (blockmodel.{hh,cc}) ---- */
 orc_model *orc_create(size_t n, size_t na, size_t nb, const uint64_t *rowptr, const uint32_t *col,

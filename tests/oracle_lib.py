@@ -69,7 +69,7 @@ def lib():
     L.orc_schedule.argtypes = [C.c_int, C.c_uint64, C.c_float, C.c_float]
     L.orc_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
     L.orc_philox_visit.restype = C.c_uint32
-    L.orc_philox_visit.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32]
+    L.orc_philox_visit.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
     L.orc_create.restype = C.c_void_p
     L.orc_create.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, _u64p, _u32p, C.c_size_t,
                              C.c_size_t, C.c_double, _u32p]

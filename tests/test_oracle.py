@@ -210,11 +210,12 @@ def test_philox_kat_and_visit_order():
     assert phx([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert phx([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
-    for n in (1, 2, 3, 5, 32, 1000, 4097):
-        p = [L.orc_philox_visit(7, 3, 11, n, i) for i in range(n)]
-        assert sorted(p) == list(range(n))
-    a = [L.orc_philox_visit(7, 3, 11, 1000, i) for i in range(1000)]
-    b = [L.orc_philox_visit(7, 3, 12, 1000, i) for i in range(1000)]
+    for na, nb in ((1, 1), (2, 1), (3, 5), (18, 14), (500, 500), (4097, 3)):
+        p = [L.orc_philox_visit(7, 3, 11, na, nb, i) for i in range(na + nb)]
+        assert sorted(p) == list(range(na + nb))
+        assert all(v < na for v in p[:na]) and all(v >= na for v in p[na:])  # type a phase, then type b
+    a = [L.orc_philox_visit(7, 3, 11, 500, 500, i) for i in range(1000)]
+    b = [L.orc_philox_visit(7, 3, 12, 500, 500, i) for i in range(1000)]
     assert a != b
 
 
