@@ -17,6 +17,10 @@
 //     per-step selects);
 //   * the pivot neighbour of the proposal depends only on the step's uniform and the row, so its label
 //     is picked up during the same walk.
+// Two waves per chain: wave 0 runs the steps, wave 1 ("feeder") prepares the NEXT chunk meanwhile --
+// visit order, row extents, own labels, LDS-DMA of the rows, the label walk into a second set of k_v
+// counters -- and hands it over through LDS at one workgroup barrier per chunk.  The memory latency of
+// a chunk's preparation (several dependent HBM round trips) is thereby off the step path entirely.
 // State on chip: the a x b quadrant of m (odd row stride: rows and columns conflict-free) and eta in
 // LDS; m_r / n_r in registers (lane i <-> block i of each type).  dS and the Hastings sums are DPP
 // butterflies; the four log_q values are one SIMT evaluation; the four uniforms of a step come from one
@@ -62,9 +66,10 @@ __device__ __forceinline__ double tab_at(const double* base, uint32_t idx) {
 }
 
 constexpr uint32_t kHistStride = 68;  // bytes per k_v row: 64 counters + pad (17 dwords: odd, conflict-free)
+constexpr uint32_t kHandWords = 5;    // v, row begin, degree, own label, pivot label
 
 template <bool EL, bool CT>
-__global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
+__global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     extern __shared__ __align__(16) uint32_t lds32[];
     const uint32_t chain = blockIdx.x;
     if (chain >= p.n_chains) return;
@@ -76,14 +81,18 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
     // LDS layout, dword offsets
     const uint32_t o_mq = 0, o_eta = ka * S;
     const uint32_t o_ids = o_eta + (EL ? K * D : 0u);
-    const uint32_t o_hist8 = o_ids + kWave * RS;
-    const uint32_t o_slow = o_hist8 + kWave * (kHistStride / 4);
+    const uint32_t o_hist8 = o_ids + kWave * RS;                             // two buffers of k_v rows
+    const uint32_t o_hand = o_hist8 + 2 * kWave * (kHistStride / 4);         // two hand-off buffers, kHandWords x 64 dwords
+    const uint32_t o_slow = o_hand + 2 * kHandWords * kWave;
+    const uint32_t o_flag = o_slow + kWave;
     int32_t* const mq = (int32_t*)(lds32 + o_mq);
     uint32_t* const eta_l = lds32 + o_eta;
     uint32_t* const ids = lds32 + o_ids;
-    uint32_t* const hist8w = lds32 + o_hist8;               // k_v byte counters, 64 rows, as dwords
-    const uint8_t* const hist8 = (const uint8_t*)hist8w;    // ... and as bytes
+    uint32_t* const hist8_base = lds32 + o_hist8;           // k_v byte counters: 2 buffers x 64 rows
+    uint32_t* const hand_base = lds32 + o_hand;             // per-chunk lane data handed from the feeder wave
     int32_t* const slow_hist = (int32_t*)(lds32 + o_slow);  // 64 counters for rows longer than 64
+    uint32_t* const stop_flag = lds32 + o_flag;
+    const bool is_main = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;  // wave 0 steps, wave 1 feeds
 
     uint8_t* const labels = p.labels + (size_t)chain * p.label_stride;
     int32_t* const m_g = p.m + (size_t)chain * ka * kb;
@@ -93,10 +102,13 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
     ChainScalars* const sc = p.scalars + chain;
     const Tables tab{p.lgamma_tab, p.lgamma_size, p.q_tab, p.q_stride, p.log_tab};
 
-    // chain state -> LDS / registers
-    for (uint32_t i = lane; i < ka * kb; i += kWave) mq[(i / kb) * S + (i % kb)] = m_g[i];
-    if (EL)
-        for (uint32_t i = lane; i < K * D; i += kWave) eta_l[i] = eta_g[i];
+    // chain state -> LDS / registers (wave 0 owns it)
+    if (is_main) {
+        for (uint32_t i = lane; i < ka * kb; i += kWave) mq[(i / kb) * S + (i % kb)] = m_g[i];
+        if (EL)
+            for (uint32_t i = lane; i < K * D; i += kWave) eta_l[i] = eta_g[i];
+        if (lane == 0) *stop_flag = 0;
+    }
     int mrA = lane < ka ? mr_g[lane] : 0, nrA = lane < ka ? nr_g[lane] : 0;
     int mrB = lane < kb ? mr_g[ka + lane] : 0, nrB = lane < kb ? nr_g[ka + lane] : 0;
     __syncthreads();
@@ -146,25 +158,22 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
             };
             Feistel order;
             order.init(phx_draw(p.seed, chain_gid, PHX_SWEEP_KEY, 2 * sweeps_total + (TB ? 1 : 0)), n_own);
+            const uint32_t n_chunks = (n_own + kWave - 1) / kWave;
 
-            for (uint32_t vi0 = 0; vi0 < n_own; vi0 += kWave) {
-                // ---- chunk: 64 nodes of the phase, lane q <-> node q ----
+            // ---- feeder wave: everything of chunk c that does not depend on the chain's block state ----
+            auto prepare = [&](uint32_t c) {
+                const uint32_t vi0 = c * kWave;
                 const uint32_t cnt = (n_own - vi0) < (uint32_t)kWave ? (n_own - vi0) : (uint32_t)kWave;
+                uint32_t* const hist8w = hist8_base + (c & 1u) * kWave * (kHistStride / 4);
+                uint32_t* const hand = hand_base + (c & 1u) * kHandWords * kWave;
                 uint32_t v_l = 0, beg_l = 0, deg_l = 0, r_l = 0, which_l = 0;
-                double ud_idx = 0., ud_R = 0., ud_tgt = 0., ud_acc = 0.;
                 if (lane < cnt) {
                     v_l = node_base + order(vi0 + lane);
                     beg_l = p.rowptr[v_l];
                     deg_l = p.rowptr[v_l + 1] - beg_l;
                     r_l = labels[v_l];  // own label: stable until the node's own step
-                    const uint64_t gs = sweeps_total * (uint64_t)n + node_base + vi0 + lane;
-                    const U4 A = phx_draw(p.seed, chain_gid, PHX_STEP_A, gs);
-                    const U4 B = phx_draw(p.seed, chain_gid, PHX_STEP_B, gs);
-                    ud_idx = u53(A.x, A.y);
-                    ud_R = u53(A.z, A.w);
-                    ud_tgt = u53(B.x, B.y);
-                    ud_acc = u53(B.z, B.w);
-                    which_l = (uint32_t)(ud_idx * (double)deg_l);  // pivot neighbour, blockmodel.cc:619
+                    const U4 A = phx_draw(p.seed, chain_gid, PHX_STEP_A, sweeps_total * (uint64_t)n + node_base + vi0 + lane);
+                    which_l = (uint32_t)(u53(A.x, A.y) * (double)deg_l);  // pivot neighbour, blockmodel.cc:619
                     if (which_l >= deg_l) which_l = deg_l ? deg_l - 1 : 0;
                 }
                 // CSR staging: the 64 rows (first row_cap ids each) HBM -> LDS by LDS-DMA, one row slot per
@@ -202,16 +211,43 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
                         }
                     }
                 }
+                hand[0 * kWave + lane] = v_l;
+                hand[1 * kWave + lane] = beg_l;
+                hand[2 * kWave + lane] = deg_l;
+                hand[3 * kWave + lane] = r_l;
+                hand[4 * kWave + lane] = (uint32_t)piv_l;
                 wfence();
+            };
 
-                // ---- the 64 steps of the chunk (metropolis_hasting.cc:42-62 each) ----
+            // ---- main wave: the 64 steps of chunk c (metropolis_hasting.cc:42-62 each) ----
+            auto run_steps = [&](uint32_t c) {
+                const uint32_t vi0 = c * kWave;
+                const uint32_t cnt = (n_own - vi0) < (uint32_t)kWave ? (n_own - vi0) : (uint32_t)kWave;
+                const uint8_t* const hist8_cur = (const uint8_t*)(hist8_base + (c & 1u) * kWave * (kHistStride / 4));
+                const uint32_t* const hand = hand_base + (c & 1u) * kHandWords * kWave;
+                const uint32_t v_l = hand[0 * kWave + lane], beg_l = hand[1 * kWave + lane];
+                const uint32_t deg_l = hand[2 * kWave + lane], r_l = hand[3 * kWave + lane];
+                const int piv_l = (int)hand[4 * kWave + lane];
+                double ud_idx = 0., ud_R = 0., ud_tgt = 0., ud_acc = 0.;
+                uint32_t which_l = 0;
+                if (lane < cnt) {  // the four uniforms of step vi0 + lane (counter-based: any lane can draw them)
+                    const uint64_t gs = sweeps_total * (uint64_t)n + node_base + vi0 + lane;
+                    const U4 A = phx_draw(p.seed, chain_gid, PHX_STEP_A, gs);
+                    const U4 B = phx_draw(p.seed, chain_gid, PHX_STEP_B, gs);
+                    ud_idx = u53(A.x, A.y);
+                    ud_R = u53(A.z, A.w);
+                    ud_tgt = u53(B.x, B.y);
+                    ud_acc = u53(B.z, B.w);
+                    which_l = (uint32_t)(ud_idx * (double)deg_l);
+                    if (which_l >= deg_l) which_l = deg_l ? deg_l - 1 : 0;
+                }
                 for (uint32_t q = 0; q < cnt; ++q) {
                     FSTAMP(0);
                     const uint32_t v = readlane(v_l, q), deg = readlane(deg_l, q), r = readlane(r_l, q);
                     const uint32_t r_loc = r - own_base;
                     const double T = CT ? T_const : temperature_of(p, sweep_step0 + node_base + vi0 + q);  // :84
                     // early LDS reads: k_v counter of lane's block, row r of m, eta[r][deg]
-                    int k = lane < k_oth ? (int)hist8[q * kHistStride + lane] : 0;
+                    int k = lane < k_oth ? (int)hist8_cur[q * kHistStride + lane] : 0;
                     const uint32_t a_rt = mq_at(r_loc, lane);
                     const int32_t m_rt = lane < k_oth ? mq[a_rt] : 0;
                     const int eta_r = (int)eta_rd(r * D + deg);
@@ -346,6 +382,17 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
                         if (T < 1.) ++u_cnt;
                     }
                 }
+            };
+
+            // chunk pipeline: the feeder is one chunk ahead; one workgroup barrier per chunk
+            if (!is_main) prepare(0);
+            __syncthreads();
+            for (uint32_t c = 0; c < n_chunks; ++c) {
+                if (is_main)
+                    run_steps(c);
+                else if (c + 1 < n_chunks)
+                    prepare(c + 1);
+                __syncthreads();
             }
         };
         run_phase(std::false_type{});
@@ -353,7 +400,9 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
 
         ++sweeps_total;
         sweeps_done = sweep + 1;
-        if (u_cnt >= p.steps_await) {  // metropolis_hasting.cc:96-98
+        if (is_main && lane == 0 && u_cnt >= p.steps_await) *stop_flag = 1;  // metropolis_hasting.cc:96-98
+        __syncthreads();
+        if (*stop_flag) {
             rate = (double)accepted_steps / (double)((sweep + 1) * (uint64_t)n);
             stopped = true;
             break;
@@ -361,8 +410,9 @@ __global__ __launch_bounds__(kWave) void sweep_fast_kernel(SweepParams p) {
     }
     if (!stopped) rate = (double)accepted_steps / (double)p.duration;  // :100
 
-    // chain state -> HBM
+    // chain state -> HBM (wave 0)
     __syncthreads();
+    if (!is_main) return;
     for (uint32_t i = lane; i < ka * kb; i += kWave) m_g[i] = mq[(i / kb) * S + (i % kb)];
     if (lane < ka) {
         mr_g[lane] = mrA;
@@ -391,7 +441,7 @@ size_t sweep_fast_lds_bytes(uint32_t ka, uint32_t kb, uint32_t maxdeg, bool eta_
     const uint32_t K = ka + kb, D = maxdeg + 1, S = kb | 1u;
     const uint32_t row_cap = maxdeg < (uint32_t)kWave ? maxdeg : (uint32_t)kWave, RS = row_cap | 1u;
     const size_t dwords = (size_t)ka * S + (eta_in_lds ? (size_t)K * D : 0) + (size_t)kWave * RS +
-                          (size_t)kWave * (kHistStride / 4) + kWave;
+                          2 * (size_t)kWave * (kHistStride / 4) + 2 * (size_t)kHandWords * kWave + kWave + 4;
     return (dwords * 4 + 15) & ~(size_t)15;
 }
 
@@ -400,7 +450,7 @@ static hipError_t launch_fast_variant(const SweepParams& p, size_t lds_bytes, hi
     hipError_t e = hipFuncSetAttribute((const void*)sweep_fast_kernel<EL, CT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((sweep_fast_kernel<EL, CT>), dim3(p.n_chains), dim3(kWave), lds_bytes, stream, p);
+    hipLaunchKernelGGL((sweep_fast_kernel<EL, CT>), dim3(p.n_chains), dim3(2 * kWave), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
