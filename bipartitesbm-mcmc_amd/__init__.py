@@ -391,3 +391,4 @@ metropolis_hasting = MetropolisHasting
 blockmodel_t = BlockModel
 
 from .distributed import ChainShard, shard_chains  # noqa: E402,F401
+from .marginalize import marginalize  # noqa: E402,F401

@@ -754,14 +754,18 @@ __global__ __launch_bounds__(kWave) void entropy_kernel(EntropyParams p) {
 // marginals: counts[v][block index within v's type] += #chains whose label of v is that block.
 // Thread = node; labels are read coalesced along the node axis of the chain-major array.
 // ------------------------------------------------------------------------------------------
-__global__ void marginals_kernel(MarginalParams p) {
+__global__ __launch_bounds__(256) void marginals_kernel(MarginalParams p) {
+    extern __shared__ __align__(16) uint32_t hist[];  // 256 node rows x (kmax | 1) counters: one row per thread
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= p.n) return;
-    const uint32_t base = v < p.na ? 0 : p.ka;
-    uint32_t* row = p.counts + (size_t)v * p.kmax;
-    for (uint32_t c = 0; c < p.n_chains; ++c) {
-        const uint32_t lab = p.labels[(size_t)c * p.label_stride + v];
-        row[lab - base] += 1;
+    const uint32_t stride = p.kmax | 1u;
+    uint32_t* row = hist + threadIdx.x * stride;
+    for (uint32_t j = 0; j < p.kmax; ++j) row[j] = 0;
+    if (v < p.n) {
+        const uint32_t base = v < p.na ? 0 : p.ka;
+        for (uint32_t c = 0; c < p.n_chains; ++c) row[(uint32_t)p.labels[(size_t)c * p.label_stride + v] - base] += 1;
+        uint32_t* out = p.counts + (size_t)v * p.kmax;
+        for (uint32_t j = 0; j < p.kmax; ++j)
+            if (row[j]) out[j] += row[j];
     }
 }
 
@@ -841,7 +845,10 @@ hipError_t launch_entropy(const EntropyParams& p, hipStream_t stream) {
 }
 
 hipError_t launch_marginals(const MarginalParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL(marginals_kernel, dim3((p.n + 255) / 256), dim3(256), 0, stream, p);
+    const size_t lds = sizeof(uint32_t) * 256 * (p.kmax | 1u);
+    hipError_t e = hipFuncSetAttribute((const void*)marginals_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(marginals_kernel, dim3((p.n + 255) / 256), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 

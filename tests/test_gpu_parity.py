@@ -178,6 +178,29 @@ def test_config2_256_chains_philox():
     assert (g.marginals_get().astype(np.int64) == want).all()
 
 
+def test_marginalize_driver_matches_oracle_samples():
+    """README-style marginalisation (burn-in, samples every f sweeps, per-node histogram, MAP label) against
+    the same schedule replayed chain by chain with the oracle."""
+    rowptr, col, na, nb = O.load_graph("southernWomen")
+    labels = O.contiguous_labels(na, nb, 5, 5)
+    chains, burn, samples, freq = 16, 3, 5, 2
+    g = gpu_model(rowptr, col, na, nb, 5, 5, 0.5, labels, n_chains=chains, rng="philox", seed=31)
+    g.shuffle_bisbm()
+    lab, counts = B.marginalize(g, burn, samples, freq)
+    want = np.zeros((na + nb, 5), dtype=np.int64)
+    for c in range(chains):
+        o = O.OracleModel(rowptr, col, na, nb, 5, 5, 0.5, labels)
+        o.seed_philox(31, c)
+        o.shuffle_bisbm()
+        o.anneal("constant", [1.0], burn * 32, BIG)
+        for _ in range(samples):
+            o.anneal("constant", [1.0], freq * 32, BIG)
+            want += B.distributed.numpy_marginals(o.memberships()[None, :], na, 5, 5)
+    assert (counts == want).all() and counts.sum() == chains * samples * 32
+    base = np.where(np.arange(32) >= na, 5, 0)
+    assert (lab == want.argmax(axis=1) + base).all()
+
+
 def test_anneal_splits_compose_on_device():
     rowptr, col, na, nb = O.load_graph("n_1000")
     labels = O.contiguous_labels(na, nb, 4, 6)
