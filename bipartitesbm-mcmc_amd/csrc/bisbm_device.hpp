@@ -372,6 +372,23 @@ __device__ __forceinline__ double exp_neg_lowprec(double y) {
     return ldexp((double)__builtin_amdgcn_exp2f(f), (int)ti);
 }
 
+// exp(z) to ~2e-7 relative for any finite z (same construction, both signs; over/underflow through ldexp)
+__device__ __forceinline__ double exp_lowprec(double z) {
+    const double t = z * 0x1.71547652b82fep+0;
+    const double ti = rint(t);
+    const float f = (float)(t - ti);
+    const int e = (int)fmax(fmin(ti, 2000.0), -2000.0);
+    return ldexp((double)__builtin_amdgcn_exp2f(f), e);
+}
+
+// Metropolis test  lhs < rhs0 * exp(z)  with the exact exp only when a 2e-7-accurate one cannot decide:
+// the outcome always equals the exact expression's (margin 1e-5 relative >> the estimate's error).
+__device__ __forceinline__ bool less_than_scaled_exp(double lhs, double rhs0, double z) {
+    const double est = rhs0 * exp_lowprec(z);
+    if (__builtin_expect(fabs(lhs - est) > 1e-5 * est, 1)) return lhs < est;
+    return lhs < rhs0 * exp(z);
+}
+
 // log_q_approx, int_part.cc:89-98.
 //
 // Branch test `k < pow(n, 1/4.)` (:90) is evaluated as k^4 < n in integers: for n < 2^32 the
@@ -392,8 +409,20 @@ __device__ inline double log_q_approx(const Tables& t, unsigned long long n, uns
     const double kPi = 3.14159265358979323846;
     const bool small = k < 65536ull && (k * k) * (k * k) < n;  // int_part.cc:90
     if (__builtin_expect(small, 0)) return lbinom_fast(t, n - 1, k - 1) - lgamma_fast(t, (long long)(k + 1));  // :73-75
-    const double sq = sqrt((double)n);
-    const double u = (double)k / sq;  // :92
+    double sq, u;
+    if (FAST) {
+        // sqrt(n) and k / sqrt(n) from one reciprocal square root (hardware estimate + two Newton steps):
+        // within 2 ulp of the correctly rounded values, no division
+        const double nd = (double)n;
+        double r = __builtin_amdgcn_rsq(nd);
+        r = r * (1.5 - 0.5 * nd * r * r);
+        r = r * (1.5 - 0.5 * nd * r * r);
+        sq = nd * r;
+        u = (double)k * r;
+    } else {
+        sq = sqrt((double)n);
+        u = (double)k / sq;  // :92
+    }
     const double C0 = 0x1.48552f88091a8p+0;    // pi / sqrt(6)
     const double C1 = 0x1.37423899a1558p-2;    // 3 / pi^2
     const double LFC = -0x1.ef8383c50bb74p+0;  // log(pi/sqrt 6) - 1.5 log 2 - log pi

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     if (__builtin_expect(T == 0., 0))
                         accept = dS < 0;
                     else
-                        accept = readlane(ud_acc, q) * accu0 < accu1 * exp(-dS * (1.0 / T));
+                        accept = less_than_scaled_exp(readlane(ud_acc, q) * accu0, accu1, -dS * (1.0 / T));
                     if (__builtin_expect(same, 0)) {
                         accept = (T != 0.);
                         dS = 0.;
