@@ -46,43 +46,37 @@ constexpr int kDppMirror = 0x140;      // lane i <-> 15-i inside each row of 16
 constexpr int kDppBcast15 = 0x142;
 constexpr int kDppBcast31 = 0x143;
 
-template <int CTRL>
+// One DPP move of a double.  The destination's previous content is left undefined (v_mov_b32_dpp with
+// no separate `old` register to initialise): with a row mask, lanes of masked-off rows hold garbage
+// afterwards, so callers must only consume lanes of enabled rows.
+template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ double dpp_f64(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, ROW_MASK, 0xF, false);
     return __hiloint2double(hi, lo);
 }
 
 // Fixed 64-leaf xor butterfly, levels 1,2,4,8,16,32: the summation tree of Philox mode (the CPU checker
 // restates the same tree).  Levels 1 and 2 are quad permutes; after them every lane of a quad holds
 // the quad's sum, so the mirror permutes pair the same partial sums as xor 4 / xor 8 would (FP add
-// is commutative: same bits); levels 16 and 32 add the four row sums as (R0+R1)+(R2+R3).  The
-// result is wave-uniform.
+// is commutative: same bits); levels 16 and 32 add the four row sums as (R0+R1)+(R2+R3): R1 += R0 and
+// R3 += R2 (row_bcast15 into rows 1,3), then R3 += R1 (row_bcast31 into rows 2,3).  Only row 3 is
+// complete at the end (rows 0 and 2 pick up garbage from the masked moves); lane 63 is returned
+// wave-uniform.
 __device__ __forceinline__ double butterfly_sum(double x) {
     x = x + dpp_f64<kDppXor1>(x);
     x = x + dpp_f64<kDppXor2>(x);
     x = x + dpp_f64<kDppHalfMirror>(x);
     x = x + dpp_f64<kDppMirror>(x);
-    // rows: R1 += R0, R3 += R2 (row_bcast15 into rows 1,3), then R3 += R1 (row_bcast31 into rows 2,3):
-    // lane 63 holds (R2+R3)+(R0+R1), the same tree as xor 16 / xor 32
-    {
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), kDppBcast15, 0xA, 0xF, false);
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), kDppBcast15, 0xA, 0xF, false);
-        const double y = __hiloint2double(hi, lo);
-        x = ((lane_id() >> 4) & 1) ? x + y : x;
-    }
-    {
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), kDppBcast31, 0xC, 0xF, false);
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), kDppBcast31, 0xC, 0xF, false);
-        const double y = __hiloint2double(hi, lo);
-        x = (lane_id() >= 32) ? x + y : x;
-    }
+    x = x + dpp_f64<kDppBcast15, 0xA>(x);
+    x = x + dpp_f64<kDppBcast31, 0xC>(x);
     return readlane(x, 63u);
 }
 
 // Two butterfly sums at once when both inputs are zero in lanes 32..63 (at most 32 leaves in use): b is
-// moved to the upper half with v_permlane32_swap and one 32-leaf butterfly per half gives both sums.
-// Same tree as butterfly_sum: its last level would only add the empty upper half (x + 0.0 = x).
+// moved to the upper half with v_permlane32_swap and one 32-leaf butterfly per half gives both sums
+// (rows 1 and 3 are the complete ones).  Same tree as butterfly_sum: its last level would only add the
+// empty upper half (x + 0.0 = x).
 __device__ __forceinline__ void butterfly_pair32(double a, double b, double& sum_a, double& sum_b) {
     const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
     const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
@@ -91,14 +85,20 @@ __device__ __forceinline__ void butterfly_pair32(double a, double b, double& sum
     x = x + dpp_f64<kDppXor2>(x);
     x = x + dpp_f64<kDppHalfMirror>(x);
     x = x + dpp_f64<kDppMirror>(x);
-    {
-        const int l = __builtin_amdgcn_update_dpp(0, __double2loint(x), kDppBcast15, 0xA, 0xF, false);
-        const int h = __builtin_amdgcn_update_dpp(0, __double2hiint(x), kDppBcast15, 0xA, 0xF, false);
-        const double y = __hiloint2double(h, l);
-        x = ((lane_id() >> 4) & 1) ? x + y : x;
-    }
+    x = x + dpp_f64<kDppBcast15, 0xA>(x);
     sum_a = readlane(x, 31u);
     sum_b = readlane(x, 63u);
+}
+
+// The sum of a 64-leaf butterfly whose leaves 32..63 are all +0.0: its level 32 adds x + 0.0 = x, so the
+// five levels of the lower half give the same bits.
+__device__ __forceinline__ double butterfly_sum_low32(double x) {
+    x = x + dpp_f64<kDppXor1>(x);
+    x = x + dpp_f64<kDppXor2>(x);
+    x = x + dpp_f64<kDppHalfMirror>(x);
+    x = x + dpp_f64<kDppMirror>(x);
+    x = x + dpp_f64<kDppBcast15, 0xA>(x);
+    return readlane(x, 31u);
 }
 
 // inclusive prefix sum of int32 over the wave: Kogge-Stone inside rows (row_shr), then the row
@@ -372,6 +372,13 @@ __device__ __forceinline__ double exp_neg_lowprec(double y) {
     return ldexp((double)__builtin_amdgcn_exp2f(f), (int)ti);
 }
 
+// 2^t the same way, for t <= 0 of moderate size
+__device__ __forceinline__ double exp2_lowprec(double t) {
+    const double ti = rint(t);
+    const float f = (float)(t - ti);  // |f| <= 0.5
+    return ldexp((double)__builtin_amdgcn_exp2f(f), (int)ti);
+}
+
 // exp(z) to ~2e-7 relative for any finite z (same construction, both signs; over/underflow through ldexp)
 __device__ __forceinline__ double exp_lowprec(double z) {
     const double t = z * 0x1.71547652b82fep+0;
@@ -407,34 +414,46 @@ __device__ __forceinline__ bool less_than_scaled_exp(double lhs, double rhs0, do
 template <bool FAST>
 __device__ inline double log_q_approx(const Tables& t, unsigned long long n, unsigned long long k, double logn_pre) {
     const double kPi = 3.14159265358979323846;
-    const bool small = k < 65536ull && (k * k) * (k * k) < n;  // int_part.cc:90
+    bool small;  // int_part.cc:90
+    if (FAST) {  // n < 2^31 here: k^4 < n needs k < 216, so k^2 and k^4 fit 24-bit multiplies
+        const uint32_t k2 = __umul24((uint32_t)k & 255u, (uint32_t)k & 255u);
+        small = (uint32_t)k < 256u && __umul24(k2 & 0xffffu, k2 & 0xffffu) < (uint32_t)n;
+    } else {
+        small = k < 65536ull && (k * k) * (k * k) < n;
+    }
     if (__builtin_expect(small, 0)) return lbinom_fast(t, n - 1, k - 1) - lgamma_fast(t, (long long)(k + 1));  // :73-75
+    const double C0 = 0x1.48552f88091a8p+0;    // pi / sqrt(6)
+    const double C1 = 0x1.37423899a1558p-2;    // 3 / pi^2
+    const double LFC = -0x1.ef8383c50bb74p+0;  // log(pi/sqrt 6) - 1.5 log 2 - log pi
     double sq, u;
     if (FAST) {
-        // sqrt(n) and k / sqrt(n) from one reciprocal square root (hardware estimate + two Newton steps):
-        // within 2 ulp of the correctly rounded values, no division
-        const double nd = (double)n;
-        double r = __builtin_amdgcn_rsq(nd);
-        r = r * (1.5 - 0.5 * nd * r * r);
-        r = r * (1.5 - 0.5 * nd * r * r);
-        sq = nd * r;
-        u = (double)k * r;
+        // sqrt(n) and k / sqrt(n) without a division: hardware reciprocal square root, one Newton step on it,
+        // then one residual step on the root itself (sq is within 1 ulp; u only has to be good to ~1e-15,
+        // it enters through terms of relative weight < 2e-9 and the tier choice)
+        const double nd = (double)(uint32_t)n;
+        const double r0 = __builtin_amdgcn_rsq(nd);
+        const double r = __builtin_fma(0.5 * r0, __builtin_fma(-(nd * r0), r0, 1.0), r0);
+        const double s0 = nd * r;
+        sq = __builtin_fma(__builtin_fma(-s0, s0, nd), 0.5 * r, s0);
+        u = (double)(uint32_t)k * r;
     } else {
         sq = sqrt((double)n);
         u = (double)k / sq;  // :92
     }
-    const double C0 = 0x1.48552f88091a8p+0;    // pi / sqrt(6)
-    const double C1 = 0x1.37423899a1558p-2;    // 3 / pi^2
-    const double LFC = -0x1.ef8383c50bb74p+0;  // log(pi/sqrt 6) - 1.5 log 2 - log pi
     if (FAST && __builtin_expect(u > 24.0, 1)) {
         // For u > 24 the iteration's limit can be written down directly: v = C0 u (1 - eps) with
         // eps = C1 (C0 u + 1) x, x = exp(-C0 u) (the first iterate's own correction changes x by
-        // < 1e-8 relative, i.e. the result by < 1e-17).  log(n) comes from the host-built table.
-        // Measured against the literal evaluation for u in [24, 70], n up to 6e7: <= 5.6e-16 relative.
-        const double x = exp_neg_lowprec(C0 * u);  // x only feeds terms of relative weight < 2e-9 (see below)
-        const double eps = C1 * (C0 * u + 1.0) * x;
-        const double corr = x * ((double)k + 0.5 * (1.0 + u * u / 2)) - eps * (2 * C0 * sq + 1.0);
-        return (LFC - logn_pre + 2 * C0 * sq) + corr;  // logn_pre = logtab[n], loaded by the caller with the other gathers
+        // < 1e-8 relative, i.e. the result by < 1e-17), and the closing formula becomes
+        //   (LFC - log n + 2 C0 sq) + x (k + (1 + u^2/2)/2) - eps (2 C0 sq + 1).
+        // log(n) comes from the host-built table; the x terms are < 1.7e-9 of the result and are evaluated
+        // with fused multiply-adds.  Against the literal evaluation for u in [24, 70], n up to 6e7: within
+        // 6e-16 relative.
+        const double x = exp2_lowprec(u * -0x1.d9af1d38092ecp+0);  // exp(-C0 u) as 2^(-C0 log2(e) u)
+        const double eps = __builtin_fma(C1 * C0, u, C1) * x;
+        const double a = __builtin_fma(u * u, 0.25, (double)(uint32_t)k + 0.5);
+        const double t2 = (2 * C0) * sq;
+        const double corr = __builtin_fma(x, a, -__builtin_fma(eps, t2, eps));
+        return ((LFC - logn_pre) + t2) + corr;  // logn_pre = logtab[n], loaded by the caller with the other gathers
     }
     if (FAST && u > 21.0) {
         double v = u, x, eps, delta;

@@ -156,6 +156,8 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
             auto mq_at = [&](uint32_t i_own, uint32_t j_oth) -> uint32_t {
                 return TB ? j_oth * S + i_own : i_own * S + j_oth;
             };
+            const double sign_tail = lane >= 8 ? 0. : ((lane < 2 || lane >= 6) ? -1. : 1.);
+            const double sign_q = lane >= 4 ? 0. : (lane < 2 ? -1. : 1.);
             Feistel order;
             order.init(phx_draw(p.seed, chain_gid, PHX_SWEEP_KEY, 2 * sweeps_total + (TB ? 1 : 0)), n_own);
             const uint32_t n_chunks = (n_own + kWave - 1) / kWave;
@@ -241,17 +243,37 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     which_l = (uint32_t)(ud_idx * (double)deg_l);
                     if (which_l >= deg_l) which_l = deg_l ? deg_l - 1 : 0;
                 }
+                // The proposal's random part (blockmodel.cc:619-628) for all 64 steps at once, lane = step: the
+                // opposite type's labels and m_r are frozen during the phase, so the R test (:622-624) and the
+                // inverse-CDF target x do not depend on the moves made inside the chunk.  Bit 31 set: uniform
+                // random block (low bits); clear: x, to be looked up in the current row m[t][.] at step time.
+                auto draw_target = [&](int32_t mrt, double u_R, double u_tgt) -> uint32_t {
+                    if (u_R * (mrt + epsK) < epsK) {  // :622-624
+                        uint32_t sR = (uint32_t)(u_tgt * Kd);
+                        if (sR >= K) sR = K - 1;
+                        return 0x80000000u | sR;
+                    }
+                    uint32_t x = (uint32_t)(u_tgt * (double)mrt);  // m_r < 2^31
+                    if (x >= (uint32_t)mrt) x = (uint32_t)mrt - 1u;
+                    return x;
+                };
+                const uint32_t prop_l = draw_target(
+                    __builtin_amdgcn_ds_bpermute((int)(((uint32_t)piv_l - oth_base) & 63u) << 2, mr_oth), ud_R, ud_tgt);
                 for (uint32_t q = 0; q < cnt; ++q) {
                     FSTAMP(0);
                     const uint32_t v = readlane(v_l, q), deg = readlane(deg_l, q), r = readlane(r_l, q);
                     const uint32_t r_loc = r - own_base;
                     const double T = CT ? T_const : temperature_of(p, sweep_step0 + node_base + vi0 + q);  // :84
                     // early LDS reads: k_v counter of lane's block, row r of m, eta[r][deg]
-                    int k = lane < k_oth ? (int)hist8_cur[q * kHistStride + lane] : 0;
+                    // (unconditional reads, idle lanes masked afterwards: the k_v bytes past k_oth are zero, and the
+                    // m reads past the quadrant stay inside the kernel's LDS allocation, see sweep_fast_lds_bytes)
+                    int k = (int)hist8_cur[q * kHistStride + lane];
                     const uint32_t a_rt = mq_at(r_loc, lane);
-                    const int32_t m_rt = lane < k_oth ? mq[a_rt] : 0;
+                    const int32_t m_rt_raw = mq[a_rt];
+                    const int32_t m_rt = lane < k_oth ? m_rt_raw : 0;
                     const int eta_r = (int)eta_rd(r * D + deg);
                     uint32_t t_piv = (uint32_t)readlane(piv_l, q);
+                    uint32_t prop = readlane(prop_l, q);
                     if (__builtin_expect(deg > (uint32_t)kWave, 0)) {  // rows longer than a wave: straight from HBM
                         const uint32_t beg = readlane(beg_l, q);
                         slow_hist[lane] = 0;
@@ -261,8 +283,10 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                         wfence();
                         k = lane < k_oth ? slow_hist[lane] : 0;
                         t_piv = labels[p.col[beg + readlane(which_l, q)]];
+                        prop = draw_target(readlane(mr_oth, t_piv - oth_base), readlane(ud_R, q), readlane(ud_tgt, q));
                     }
-                    const int w_piv = lane < k_own ? mq[mq_at(lane, t_piv - oth_base)] : 0;
+                    // column t of m over v's own type; lanes >= k_own read past it and are ignored by the ballot
+                    const int w_piv = mq[mq_at(lane, t_piv - oth_base)];
                     FSTAMP(1);
 
                     // ---- proposal: single_vertex_change, blockmodel.cc:613-637 ----
@@ -272,19 +296,12 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     } else if (__builtin_expect(deg == 0, 0)) {
                         s = (uint32_t)(readlane(ud_idx, q) * Kd);
                         if (s >= K) s = K - 1;
-                    } else {
-                        const int32_t mrt = readlane(mr_oth, t_piv - oth_base);
-                        const double u_tgt = readlane(ud_tgt, q);
-                        if (__builtin_expect(readlane(ud_R, q) * (mrt + epsK) < epsK, 0)) {  // :622-624
-                            s = (uint32_t)(u_tgt * Kd);
-                            if (s >= K) s = K - 1;
-                        } else {  // integer inverse CDF over row m[t][.] restricted to v's own type (:627-628)
-                            uint32_t x = (uint32_t)(u_tgt * (double)mrt);  // m_r < 2^31
-                            if (x >= (uint32_t)mrt) x = (uint32_t)mrt - 1u;
-                            const int scan = wave_inclusive_scan(w_piv);
-                            const unsigned long long hit = __ballot(lane < k_own && (uint32_t)scan > x);
-                            s = hit ? own_base + (uint32_t)__ffsll((long long)hit) - 1 : own_base + k_own - 1;
-                        }
+                    } else if (__builtin_expect((int32_t)prop < 0, 0)) {
+                        s = prop & 0x7fffffffu;
+                    } else {  // integer inverse CDF over row m[t][.] restricted to v's own type (:627-628)
+                        const int scan = wave_inclusive_scan(w_piv);
+                        const unsigned long long hit = __ballot(lane < k_own && (uint32_t)scan > prop);
+                        s = hit ? own_base + (uint32_t)__ffsll((long long)hit) - 1 : own_base + k_own - 1;
                     }
                     FSTAMP(2);
 
@@ -297,7 +314,8 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     const uint32_t s_loc = s_eff - own_base;
                     const int ideg = (int)deg;
                     const uint32_t a_st = mq_at(s_loc, lane);
-                    const int32_t m_st = lane < k_oth ? mq[a_st] : 0;
+                    const int32_t m_st_raw = mq[a_st];
+                    const int32_t m_st = lane < k_oth ? m_st_raw : 0;
                     const int eta_s = (int)eta_rd(s_eff * D + deg);
                     const int m0r = readlane(mr_own, r_loc);
                     const int m0s = readlane(mr_own, s_loc);
@@ -336,10 +354,12 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     FSTAMP(5);
                     double d = (L1 + L2) - (L3 + L4);
                     // fold the scalar terms into leaves 0..7 / 0..3 with their signs
-                    const bool neg_tail = (lane < 2) || (lane >= 6);  // -lg(m0r+1) -lg(m0s+1) ... -lg(eta_r) -lg(eta_s+2)
-                    d = lane < 8 ? d + (neg_tail ? -tail_lg : tail_lg) : d;
-                    d = lane < 4 ? d + (lane < 2 ? -lq : lq) : d;
-                    double dS = butterfly_sum(d);
+                    // (sign_tail: -lg(m0r+1) -lg(m0s+1) +lg(m1r+1) +lg(m1s+1) +lg(eta_r+1) +lg(eta_s+1) -lg(eta_r)
+                    // -lg(eta_s+2), zero from lane 8 on; sign_q: -,-,+,+, zero from lane 4 on.  x * (+-1) is exact and
+                    // idle lanes add a zero: the table values are finite)
+                    d = d + tail_lg * sign_tail;
+                    d = d + lq * sign_q;
+                    double dS = k_oth <= 32u ? butterfly_sum_low32(d) : butterfly_sum(d);
                     FSTAMP(6);
                     // accept (:47-61): T == 0: dS < 0;  else u < exp(-dS/T) accu1/accu0
                     bool accept;
@@ -442,7 +462,10 @@ size_t sweep_fast_lds_bytes(uint32_t ka, uint32_t kb, uint32_t maxdeg, bool eta_
     const uint32_t row_cap = maxdeg < (uint32_t)kWave ? maxdeg : (uint32_t)kWave, RS = row_cap | 1u;
     const size_t dwords = (size_t)ka * S + (eta_in_lds ? (size_t)K * D : 0) + (size_t)kWave * RS +
                           2 * (size_t)kWave * (kHistStride / 4) + 2 * (size_t)kHandWords * kWave + kWave + 4;
-    return (dwords * 4 + 15) & ~(size_t)15;
+    // the step reads m[.][lane] for all 64 lanes whatever ka, kb are (idle lanes are masked after the read):
+    // dword index <= 63 * S + 63 must be inside the allocation
+    const size_t reach = 63 * (size_t)S + 64;
+    return ((dwords > reach ? dwords : reach) * 4 + 15) & ~(size_t)15;
 }
 
 template <bool EL, bool CT>
