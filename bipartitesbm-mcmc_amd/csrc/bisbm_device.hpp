@@ -113,6 +113,16 @@ __device__ __forceinline__ int wave_inclusive_scan(int x) {
     return x;
 }
 
+// the same scan when only lanes 0..31 are consumed (no carry into rows 2,3 from row 1 needed)
+__device__ __forceinline__ int wave_inclusive_scan32(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, kDppBcast15, 0xA, 0xF, false);
+    return x;
+}
+
 // ------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11) and the production draw definitions
 // ------------------------------------------------------------------------------------------

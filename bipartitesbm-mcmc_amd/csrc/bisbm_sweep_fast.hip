@@ -68,7 +68,24 @@ __device__ __forceinline__ double tab_at(const double* base, uint32_t idx) {
 constexpr uint32_t kHistStride = 68;  // bytes per k_v row: 64 counters + pad (17 dwords: odd, conflict-free)
 constexpr uint32_t kHandWords = 5;    // v, row begin, degree, own label, pivot label
 
-template <bool EL, bool CT>
+// 2^t for moderate |t| to ~1e-7 relative: f64 range reduction, v_exp_f32 on the fraction.  The integer part goes
+// through v_cvt_i32_f64 itself (saturating, NaN -> 0), so any finite or infinite t is safe.
+__device__ __forceinline__ double exp2_filter(double t) {
+    const double ti = rint(t);
+    const float f = (float)(t - ti);
+    int e;
+    __asm__("v_cvt_i32_f64 %0, %1" : "=v"(e) : "v"(ti));
+    return ldexp((double)__builtin_amdgcn_exp2f(f), e);
+}
+
+// a double constant held in a vector register pair for the whole kernel (64-bit literals are not encodable
+// and the scalar file is full: without this the hot loop rebuilds them with s_mov pairs at every use)
+#define BISBM_PIN(name, value) \
+    double name = (value);     \
+    __asm__ volatile("" : "+v"(name))
+
+// EL: eta in LDS.  CT: constant schedule.  K32: both block counts <= 32 (five-level scans and sums).
+template <bool EL, bool CT, bool K32>
 __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     extern __shared__ __align__(16) uint32_t lds32[];
     const uint32_t chain = blockIdx.x;
@@ -130,6 +147,18 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     const uint32_t n = p.n;
     const uint64_t all_sweeps = p.duration / n;
     const double T_const = (double)p.kw0;  // CT: constant schedule (metropolis_hasting.cc:25-28)
+    // m_r <= E: with E + maxdeg inside the log_q table no step can use the closed-form tier of the hot path
+    const bool never_direct = (p.rowptr[n] >> 1) + p.maxdeg <= (uint32_t)kQNmax;
+    const bool track_min = !CT || T_const < 1.;  // the early-stop bookkeeping can only ever fire below T = 1
+    // constants of the hot step (log_q closed form, accept filter)
+    BISBM_PIN(c_l2e, 0x1.71547652b82fep+0);        // log2(e)
+    BISBM_PIN(c_tol, 1e-5);                        // accept filter margin
+    BISBM_PIN(c_nc0l2e, -0x1.d9af1d38092ecp+0);    // -(pi/sqrt 6) log2(e)
+    BISBM_PIN(c_c1c0, 0x1.37423899a1558p-2 * 0x1.48552f88091a8p+0);  // (3/pi^2)(pi/sqrt 6)
+    BISBM_PIN(c_c1, 0x1.37423899a1558p-2);         // 3/pi^2
+    BISBM_PIN(c_2c0, 2 * 0x1.48552f88091a8p+0);    // 2 pi/sqrt 6
+    BISBM_PIN(c_lfc, -0x1.ef8383c50bb74p+0);       // log(pi/sqrt 6) - 1.5 log 2 - log pi
+    BISBM_PIN(c_576, 576.0);                       // 24^2: tier test k^2 > 576 n
     uint64_t accepted_steps = 0, u_cnt = 0, sweeps_done = 0;
     double entropy_min = INFINITY;  // metropolis_hasting.cc:75
     double rate = 0.;
@@ -158,6 +187,13 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
             };
             const double sign_tail = lane >= 8 ? 0. : ((lane < 2 || lane >= 6) ? -1. : 1.);
             const double sign_q = lane >= 4 ? 0. : (lane < 2 ? -1. : 1.);
+            const int eoff_l = (lane & 7u) < 6 ? 1 : ((lane & 1u) ? 2 : 0);       // eta_r+1, eta_s+1, eta_r, eta_s+2
+            const int dq_l = (lane & 2u) ? ((lane & 1u) ? 1 : -1) : 0;            // n_r - 1, n_s + 1 in lanes 2,3 (mod 4)
+            const int dsgn_l = dq_l;                                              // -deg, +deg in the same lanes
+            const int odd_mask_l = (lane & 1u) ? -1 : 0;
+            const int eta_mask_l = (lane & 4u) ? -1 : 0;                          // lanes 4..7 (mod 8): the eta terms
+            const int toff_l = (lane & 4u) ? eoff_l : 1;                          // table index = argument + this
+            const int oth_mask_l = lane < k_oth ? -1 : 0;
             Feistel order;
             order.init(phx_draw(p.seed, chain_gid, PHX_SWEEP_KEY, 2 * sweeps_total + (TB ? 1 : 0)), n_own);
             const uint32_t n_chunks = (n_own + kWave - 1) / kWave;
@@ -246,7 +282,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                 // The proposal's random part (blockmodel.cc:619-628) for all 64 steps at once, lane = step: the
                 // opposite type's labels and m_r are frozen during the phase, so the R test (:622-624) and the
                 // inverse-CDF target x do not depend on the moves made inside the chunk.  Bit 31 set: uniform
-                // random block (low bits); clear: x, to be looked up in the current row m[t][.] at step time.
+                // random block (low bits); clear: x, to be looked up in the current column m[.][t] at step time.
                 auto draw_target = [&](int32_t mrt, double u_R, double u_tgt) -> uint32_t {
                     if (u_R * (mrt + epsK) < epsK) {  // :622-624
                         uint32_t sR = (uint32_t)(u_tgt * Kd);
@@ -257,24 +293,40 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     if (x >= (uint32_t)mrt) x = (uint32_t)mrt - 1u;
                     return x;
                 };
-                const uint32_t prop_l = draw_target(
-                    __builtin_amdgcn_ds_bpermute((int)(((uint32_t)piv_l - oth_base) & 63u) << 2, mr_oth), ud_R, ud_tgt);
-                for (uint32_t q = 0; q < cnt; ++q) {
-                    FSTAMP(0);
+                // Per-lane inputs of the hot step.  prop_l bit 31 sends the step down the general path: uniform
+                // random target, a single own block, empty or over-long rows, T == 0, small graphs.
+                const uint32_t tloc_l = ((uint32_t)piv_l - oth_base) & 63u;
+                const uint32_t rloc_l = r_l - own_base;
+                uint32_t prop_l = draw_target(__builtin_amdgcn_ds_bpermute((int)(tloc_l << 2), mr_oth), ud_R, ud_tgt);
+                if (k_own == 1u || deg_l == 0u || deg_l > (uint32_t)kWave || (CT && T_const == 0.) || never_direct)
+                    prop_l |= 0x80000000u;
+
+                // anneal()'s bookkeeping after a step, metropolis_hasting.cc:85-94
+                auto book = [&](bool ok, double T) {
+                    if (ok) ++accepted_steps;
+                    if (track_min) {
+                        if (ok && cum_dS < entropy_min) {
+                            entropy_min = cum_dS;
+                            u_cnt = 0;
+                        }
+                        if (T < 1.) ++u_cnt;
+                    }
+                };
+
+                // ---- any step (all the rare cases included): the definition the hot path below specialises ----
+                auto step_general = [&](uint32_t q, double T) {
                     const uint32_t v = readlane(v_l, q), deg = readlane(deg_l, q), r = readlane(r_l, q);
                     const uint32_t r_loc = r - own_base;
-                    const double T = CT ? T_const : temperature_of(p, sweep_step0 + node_base + vi0 + q);  // :84
-                    // early LDS reads: k_v counter of lane's block, row r of m, eta[r][deg]
-                    // (unconditional reads, idle lanes masked afterwards: the k_v bytes past k_oth are zero, and the
-                    // m reads past the quadrant stay inside the kernel's LDS allocation, see sweep_fast_lds_bytes)
+                    // k_v counter of lane's block, row r of m, eta[r][deg] (unconditional reads, idle lanes masked
+                    // afterwards: the k_v bytes past k_oth are zero, and the m reads past the quadrant stay inside
+                    // the kernel's LDS allocation, see sweep_fast_lds_bytes)
                     int k = (int)hist8_cur[q * kHistStride + lane];
                     const uint32_t a_rt = mq_at(r_loc, lane);
                     const int32_t m_rt_raw = mq[a_rt];
                     const int32_t m_rt = lane < k_oth ? m_rt_raw : 0;
                     const int eta_r = (int)eta_rd(r * D + deg);
                     uint32_t t_piv = (uint32_t)readlane(piv_l, q);
-                    uint32_t prop = readlane(prop_l, q);
-                    if (__builtin_expect(deg > (uint32_t)kWave, 0)) {  // rows longer than a wave: straight from HBM
+                    if (deg > (uint32_t)kWave) {  // rows longer than a wave: straight from HBM
                         const uint32_t beg = readlane(beg_l, q);
                         slow_hist[lane] = 0;
                         wfence();
@@ -283,31 +335,32 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                         wfence();
                         k = lane < k_oth ? slow_hist[lane] : 0;
                         t_piv = labels[p.col[beg + readlane(which_l, q)]];
-                        prop = draw_target(readlane(mr_oth, t_piv - oth_base), readlane(ud_R, q), readlane(ud_tgt, q));
                     }
                     // column t of m over v's own type; lanes >= k_own read past it and are ignored by the ballot
                     const int w_piv = mq[mq_at(lane, t_piv - oth_base)];
-                    FSTAMP(1);
 
                     // ---- proposal: single_vertex_change, blockmodel.cc:613-637 ----
                     uint32_t s;
-                    if (__builtin_expect(k_own == 1, 0)) {
+                    if (k_own == 1) {
                         s = r;
-                    } else if (__builtin_expect(deg == 0, 0)) {
+                    } else if (deg == 0) {
                         s = (uint32_t)(readlane(ud_idx, q) * Kd);
                         if (s >= K) s = K - 1;
-                    } else if (__builtin_expect((int32_t)prop < 0, 0)) {
-                        s = prop & 0x7fffffffu;
-                    } else {  // integer inverse CDF over row m[t][.] restricted to v's own type (:627-628)
-                        const int scan = wave_inclusive_scan(w_piv);
-                        const unsigned long long hit = __ballot(lane < k_own && (uint32_t)scan > prop);
-                        s = hit ? own_base + (uint32_t)__ffsll((long long)hit) - 1 : own_base + k_own - 1;
+                    } else {
+                        const uint32_t prop =
+                            draw_target(readlane(mr_oth, t_piv - oth_base), readlane(ud_R, q), readlane(ud_tgt, q));
+                        if ((int32_t)prop < 0) {
+                            s = prop & 0x7fffffffu;
+                        } else {  // integer inverse CDF over column m[.][t] restricted to v's own type (:627-628)
+                            const int scan = wave_inclusive_scan(w_piv);
+                            const unsigned long long hit = __ballot(lane < k_own && (uint32_t)scan > prop);
+                            s = hit ? own_base + (uint32_t)__ffsll((long long)hit) - 1 : own_base + k_own - 1;
+                        }
                     }
-                    FSTAMP(2);
 
                     // ---- transition_ratio, metropolis_hasting.cc:103-192 (production arithmetic) ----
-                    // r == s (always accepted at T > 0, :109-112) and cross-type targets (dS = +inf, :121-123) are
-                    // rare: same straight-line code with s replaced by r, outcome overridden.
+                    // r == s (always accepted at T > 0, :109-112) and cross-type targets (dS = +inf, :121-123):
+                    // same straight-line code with s replaced by r, outcome overridden.
                     const bool same = (r == s);
                     const bool cross = !same && ((r < ka) != (s < ka));
                     const uint32_t s_eff = (same || cross) ? r : s;
@@ -336,9 +389,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     const double L2 = tab_at(tab.lg, (uint32_t)(m_st + 1));
                     const double L3 = tab_at(tab.lg, (uint32_t)(m_rt + 1) - kk);
                     const double L4 = tab_at(tab.lg, (uint32_t)(m_st + 1) + kk);
-                    FSTAMP(3);
-                    // Hastings sums: on-chip data only, they run while the table gathers are in flight.
-                    // k == 0 lanes give exact zeros (0 * x = +0, identical table entries cancel): no branch.
+                    // Hastings sums.  k == 0 lanes give exact zeros (0 * x = +0, identical table entries cancel).
                     const double a0 = k * (m_st + eps) * inv_oth;
                     const double a1 = k * (m_rt - k + eps) * inv_oth;
                     double accu0, accu1;
@@ -348,10 +399,8 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                         accu0 = butterfly_sum(a0);
                         accu1 = butterfly_sum(a1);
                     }
-                    if (__builtin_expect(deg == 0, 0)) accu0 = accu1 = 1.;
-                    FSTAMP(4);
+                    if (deg == 0) accu0 = accu1 = 1.;
                     const double lq = log_q<true>(tab, qn, qk, logn);
-                    FSTAMP(5);
                     double d = (L1 + L2) - (L3 + L4);
                     // fold the scalar terms into leaves 0..7 / 0..3 with their signs
                     // (sign_tail: -lg(m0r+1) -lg(m0s+1) +lg(m1r+1) +lg(m1s+1) +lg(eta_r+1) +lg(eta_s+1) -lg(eta_r)
@@ -360,21 +409,21 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     d = d + tail_lg * sign_tail;
                     d = d + lq * sign_q;
                     double dS = k_oth <= 32u ? butterfly_sum_low32(d) : butterfly_sum(d);
-                    FSTAMP(6);
                     // accept (:47-61): T == 0: dS < 0;  else u < exp(-dS/T) accu1/accu0
                     bool accept;
-                    if (__builtin_expect(T == 0., 0))
+                    if (T == 0.)
                         accept = dS < 0;
                     else
                         accept = less_than_scaled_exp(readlane(ud_acc, q) * accu0, accu1, -dS * (1.0 / T));
-                    if (__builtin_expect(same, 0)) {
+                    if (same) {
                         accept = (T != 0.);
                         dS = 0.;
                     }
-                    if (__builtin_expect(cross, 0)) accept = false;
-                    FSTAMP(7);
+                    if (cross) accept = false;
                     // ---- apply_mcmc_moves, blockmodel.cc:461-503 ----
-                    const bool ok = accept && (n_r_r - 1 != 0);  // :467-471 veto after the draw
+                    // (every lane holds the same outcome; taking it through a ballot tells the compiler so, and the
+                    // step counters stay scalar)
+                    const bool ok = __builtin_amdgcn_ballot_w64(accept && (n_r_r - 1 != 0)) != 0;  // :467-471 veto
                     if (ok && !same) {
                         wfence();
                         if (lane == 0) {
@@ -391,17 +440,159 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                         cum_dS += dS;  // :500
                         wfence();
                     }
-                    FSTAMP(8);
-                    // ---- bookkeeping of anneal(), metropolis_hasting.cc:85-94 ----
-                    if (ok) ++accepted_steps;
-                    if (!CT || T_const < 1.) {
-                        if (ok && cum_dS < entropy_min) {
+                    book(ok, T);
+                };
+
+                // ---- the 64 steps.  Hot path: 1 <= deg <= 64, target drawn from column m[.][t], T > 0 ----
+                const unsigned long long last_own_bit = 1ull << (k_own - 1);
+                const double invT_const = 1.0 / T_const;
+                // One step.  Early returns only (each is a jump to the loop latch); the rare cases leave through
+                // step_general at the top, before anything is computed.
+                auto booked = [&](uint32_t ok_i, double T) {  // ok_i = 1: counts as accepted (metropolis_hasting.cc:87)
+                    accepted_steps += ok_i;
+                    if (track_min) {
+                        if (ok_i && cum_dS < entropy_min) {
                             entropy_min = cum_dS;
                             u_cnt = 0;
                         }
                         if (T < 1.) ++u_cnt;
                     }
-                }
+                };
+                auto step = [&](uint32_t q) {
+                    const double T = CT ? T_const : temperature_of(p, sweep_step0 + node_base + vi0 + q);  // :84
+                    FSTAMP(0);
+                    const uint32_t prop = readlane(prop_l, q);
+                    if (__builtin_expect((int32_t)prop < 0 || (!CT && T == 0.), 0)) {
+                        step_general(q, T);
+                        return;
+                    }
+                    const uint32_t deg = readlane(deg_l, q), r_loc = readlane(rloc_l, q);
+                    const uint32_t t_loc = readlane(tloc_l, q);
+                    // early LDS reads: k_v counter of lane's block, row r of m, column t of m over v's own type
+                    const int k = (int)hist8_cur[q * kHistStride + lane];
+                    const uint32_t a_rt = mq_at(r_loc, lane);
+                    const int32_t m_rt_raw = mq[a_rt];
+                    const int w_piv = mq[mq_at(lane, t_loc)];
+                    const int n_r_r = readlane(nr_own, r_loc);
+                    FSTAMP(1);
+                    // integer inverse CDF (:627-628): first own block whose running total exceeds x.  Lanes past
+                    // k_own hold garbage, but block k_own - 1 always qualifies (its total is m_r[t] > x).
+                    const int scan = K32 ? wave_inclusive_scan32(w_piv) : wave_inclusive_scan(w_piv);
+                    const unsigned long long hit = __builtin_amdgcn_ballot_w64((uint32_t)scan > prop) | last_own_bit;
+                    const uint32_t s_loc = (uint32_t)__builtin_ctzll(hit);
+                    FSTAMP(2);
+                    if (s_loc == r_loc) {  // r == s: accepted as is (T > 0 here), nothing changes (:109-112)
+                        booked(n_r_r != 1, T);
+                        return;
+                    }
+                    const uint32_t r = own_base + r_loc, s = own_base + s_loc;
+                    const int ideg = (int)deg;
+                    const uint32_t a_st = mq_at(s_loc, lane);
+                    const int32_t m_st_raw = mq[a_st];
+                    const int eta_r = (int)eta_rd(r * D + deg);
+                    const int eta_s = (int)eta_rd(s * D + deg);
+                    const int32_t m_rt = m_rt_raw & oth_mask_l;  // idle lanes: 0
+                    const int32_t m_st = m_st_raw & oth_mask_l;
+                    const int m0r = readlane(mr_own, r_loc);
+                    const int m0s = readlane(mr_own, s_loc);
+                    const int n_r_s = readlane(nr_own, s_loc);
+                    // lanes 0..7 (pattern repeated): the scalar lgamma terms (:164-177); lanes 0..3: log_q arguments.
+                    // Lane-pattern selects as bit arithmetic on per-lane constant masks (a ^ ((a ^ b) & mask)).
+                    const int mm = m0r ^ ((m0r ^ m0s) & odd_mask_l);  // odd lanes: s, even lanes: r
+                    const int ee = eta_r ^ ((eta_r ^ eta_s) & odd_mask_l);
+                    const int qn = mm + __mul24(ideg, dsgn_l);        // m0r, m0s, m0r - deg, m0s + deg
+                    const uint32_t tail_idx = (uint32_t)((qn ^ ((qn ^ ee) & eta_mask_l)) + toff_l);
+                    const int qk = (n_r_r ^ ((n_r_r ^ n_r_s) & odd_mask_l)) + dq_l;
+                    const double tail_lg = tab_at(tab.lg, tail_idx);
+                    const double logn = tab_at(tab.logtab, (uint32_t)qn);  // log(n) of the log_q arguments
+                    const uint32_t kk = (uint32_t)k;
+                    const double L1 = tab_at(tab.lg, (uint32_t)(m_rt + 1));
+                    const double L2 = tab_at(tab.lg, (uint32_t)(m_st + 1));
+                    const double L3 = tab_at(tab.lg, (uint32_t)(m_rt + 1) - kk);
+                    const double L4 = tab_at(tab.lg, (uint32_t)(m_st + 1) + kk);
+                    FSTAMP(3);
+                    // Hastings sums: on-chip data only, they run while the table gathers are in flight.
+                    // k == 0 lanes give exact zeros (0 * x = +0, identical table entries cancel).
+                    const double a0 = k * (m_st + eps) * inv_oth;
+                    const double a1 = k * (m_rt - k + eps) * inv_oth;
+                    double accu0, accu1;
+                    if (K32) {
+                        butterfly_pair32(a0, a1, accu0, accu1);
+                    } else {
+                        accu0 = butterfly_sum(a0);
+                        accu1 = butterfly_sum(a1);
+                    }
+                    FSTAMP(4);
+                    // log_q of the four (n, k) pairs, one per lane (mod 4).  Tier u = k / sqrt(n) > 24 above the table
+                    // (k^2 > 576 n, evaluated in doubles: the tiers agree to 6e-16 around the boundary) is the closed
+                    // form of bisbm_device.hpp (log_q_approx<true>) written out on pinned constants; anything else
+                    // goes through log_q<true>.
+                    double lq;
+                    {
+                        const int qk2 = qk < qn ? qk : qn;
+                        const double nd = (double)qn, kd = (double)qk2;
+                        const bool direct = qn > kQNmax && kd * kd > c_576 * nd;
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!direct) == 0, 1)) {  // (lanes repeat mod 4)
+                            const double r0 = __builtin_amdgcn_rsq(nd);
+                            const double rr = __builtin_fma(0.5 * r0, __builtin_fma(-(nd * r0), r0, 1.0), r0);
+                            const double s0 = nd * rr;
+                            const double sq = __builtin_fma(__builtin_fma(-s0, s0, nd), 0.5 * rr, s0);
+                            const double u = kd * rr;
+                            const double x = exp2_filter(u * c_nc0l2e);
+                            const double e1 = __builtin_fma(c_c1c0, u, c_c1) * x;
+                            const double aa = __builtin_fma(u * u, 0.25, kd + 0.5);
+                            const double t2 = c_2c0 * sq;
+                            const double corr = __builtin_fma(x, aa, -__builtin_fma(e1, t2, e1));
+                            lq = ((c_lfc - logn) + t2) + corr;
+                        } else {
+                            lq = log_q<true>(tab, qn, qk, logn);
+                        }
+                    }
+                    FSTAMP(5);
+                    double d = (L1 + L2) - (L3 + L4);
+                    d = d + tail_lg * sign_tail;  // scalar terms folded into leaves 0..7 / 0..3, see step_general
+                    d = d + lq * sign_q;
+                    const double dS = K32 ? butterfly_sum_low32(d) : butterfly_sum(d);
+                    FSTAMP(6);
+                    // accept (:47-61): u accu0 < accu1 exp(-dS/T), decided on a 1e-7-accurate exponential unless
+                    // the two sides are within 1e-5 of each other (then the exact one decides)
+                    const double z = -dS * (CT ? invT_const : 1.0 / T);
+                    const double est = accu1 * exp2_filter(z * c_l2e);
+                    const double lhs = readlane(ud_acc, q) * accu0;
+                    const unsigned long long b_lt = __builtin_amdgcn_ballot_w64(lhs < est);
+                    const unsigned long long b_far = __builtin_amdgcn_ballot_w64(fabs(lhs - est) > c_tol * est);
+                    FSTAMP(7);
+                    if ((b_lt | ~b_far) == 0) {  // clearly rejected
+                        booked(0, T);
+                        return;
+                    }
+                    unsigned long long b_acc = b_lt;
+                    if (__builtin_expect(b_far == 0, 0)) b_acc = __builtin_amdgcn_ballot_w64(lhs < accu1 * exp(z));
+                    if (b_acc == 0 || n_r_r == 1) {  // (:467-471: veto after the draw)
+                        booked(0, T);
+                        return;
+                    }
+                    // ---- apply_mcmc_moves, blockmodel.cc:461-503 ----
+                    const uint32_t v = readlane(v_l, q);
+                    wfence();
+                    if (lane == 0) {
+                        eta_wr(r * D + deg, (uint32_t)(eta_r - 1));
+                        eta_wr(s * D + deg, (uint32_t)(eta_s + 1));
+                        labels[v] = (uint8_t)s;
+                    }
+                    const int dl = (int)min(lane ^ r_loc, 1u) - (int)min(lane ^ s_loc, 1u);  // +1 on lane s_loc, -1 on r_loc
+                    mr_own += __mul24(ideg, dl);
+                    nr_own += dl;
+                    if (lane < k_oth) {  // k == 0: rewrites the same values
+                        mq[a_rt] = m_rt - k;
+                        mq[a_st] = m_st + k;
+                    }
+                    cum_dS += dS;  // :500
+                    wfence();
+                    FSTAMP(8);
+                    booked(1, T);
+                };
+                for (uint32_t q = 0; q < cnt; ++q) step(q);
             };
 
             // chunk pipeline: the feeder is one chunk ahead; one workgroup barrier per chunk
@@ -422,7 +613,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
         sweeps_done = sweep + 1;
         if (is_main && lane == 0 && u_cnt >= p.steps_await) *stop_flag = 1;  // metropolis_hasting.cc:96-98
         __syncthreads();
-        if (*stop_flag) {
+        if (__builtin_amdgcn_readfirstlane((int)*stop_flag)) {  // (scalar: the sweep loop has no divergent exit)
             rate = (double)accepted_steps / (double)((sweep + 1) * (uint64_t)n);
             stopped = true;
             break;
@@ -468,13 +659,19 @@ size_t sweep_fast_lds_bytes(uint32_t ka, uint32_t kb, uint32_t maxdeg, bool eta_
     return ((dwords > reach ? dwords : reach) * 4 + 15) & ~(size_t)15;
 }
 
-template <bool EL, bool CT>
-static hipError_t launch_fast_variant(const SweepParams& p, size_t lds_bytes, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)sweep_fast_kernel<EL, CT>,
+template <bool EL, bool CT, bool K32>
+static hipError_t launch_fast_variant3(const SweepParams& p, size_t lds_bytes, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)sweep_fast_kernel<EL, CT, K32>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((sweep_fast_kernel<EL, CT>), dim3(p.n_chains), dim3(2 * kWave), lds_bytes, stream, p);
+    hipLaunchKernelGGL((sweep_fast_kernel<EL, CT, K32>), dim3(p.n_chains), dim3(2 * kWave), lds_bytes, stream, p);
     return hipGetLastError();
+}
+
+template <bool EL, bool CT>
+static hipError_t launch_fast_variant(const SweepParams& p, size_t lds_bytes, hipStream_t stream) {
+    return (p.ka <= 32u && p.kb <= 32u) ? launch_fast_variant3<EL, CT, true>(p, lds_bytes, stream)
+                                        : launch_fast_variant3<EL, CT, false>(p, lds_bytes, stream);
 }
 
 hipError_t launch_sweep_fast(const SweepParams& p, size_t /*generic_lds_bytes*/, hipStream_t stream) {
