@@ -372,24 +372,8 @@ __device__ inline double get_v(double u) {  // int_part.cc:77-87
     return v;
 }
 
-// exp(-y) to ~1e-7 relative for y in [0, 700]: f64 range reduction, v_exp_f32 on the fraction.
-// Used only where the value enters the result with a relative weight below 2e-9 (log_q tier u > 24:
-// every term that contains x = exp(-C0 u) is < 1.7e-9 of the result, so 1e-7 on x is < 2e-16 on it).
-__device__ __forceinline__ double exp_neg_lowprec(double y) {
-    const double t = -y * 0x1.71547652b82fep+0;  // * log2(e)
-    const double ti = rint(t);
-    const float f = (float)(t - ti);  // |f| <= 0.5
-    return ldexp((double)__builtin_amdgcn_exp2f(f), (int)ti);
-}
-
-// 2^t the same way, for t <= 0 of moderate size
-__device__ __forceinline__ double exp2_lowprec(double t) {
-    const double ti = rint(t);
-    const float f = (float)(t - ti);  // |f| <= 0.5
-    return ldexp((double)__builtin_amdgcn_exp2f(f), (int)ti);
-}
-
-// exp(z) to ~2e-7 relative for any finite z (same construction, both signs; over/underflow through ldexp)
+// exp(z) to ~2e-7 relative for any finite z: f64 range reduction, v_exp_f32 on the fraction (over/underflow
+// through ldexp)
 __device__ __forceinline__ double exp_lowprec(double z) {
     const double t = z * 0x1.71547652b82fep+0;
     const double ti = rint(t);
@@ -404,6 +388,56 @@ __device__ __forceinline__ bool less_than_scaled_exp(double lhs, double rhs0, do
     const double est = rhs0 * exp_lowprec(z);
     if (__builtin_expect(fabs(lhs - est) > 1e-5 * est, 1)) return lhs < est;
     return lhs < rhs0 * exp(z);
+}
+
+// Constants of the closed-form tier of log_q_approx (u = k / sqrt(n) > 24), see log_q_closed.
+struct LogQConsts {
+    double nc0l2e;  // -(pi/sqrt 6) log2(e)
+    double c1c0;    // (3/pi^2)(pi/sqrt 6)
+    double c1;      // 3/pi^2
+    double c2c0;    // 2 pi/sqrt 6
+    double lfc;     // log(pi/sqrt 6) - 1.5 log 2 - log pi
+};
+__device__ __forceinline__ LogQConsts log_q_consts() {
+    return {-0x1.d9af1d38092ecp+0, 0x1.37423899a1558p-2 * 0x1.48552f88091a8p+0, 0x1.37423899a1558p-2,
+            2 * 0x1.48552f88091a8p+0, -0x1.ef8383c50bb74p+0};
+}
+
+// 2^t for t <= 0 of moderate size to ~1e-7 relative: f64 range reduction, v_exp_f32 on the fraction.  The
+// integer part goes through v_cvt_i32_f64 itself (saturating, NaN -> 0), so any t is safe.
+__device__ __forceinline__ double exp2_filter(double t) {
+    const double ti = rint(t);
+    const float f = (float)(t - ti);  // |f| <= 0.5
+    int e;
+    __asm__("v_cvt_i32_f64 %0, %1" : "=v"(e) : "v"(ti));
+    return ldexp((double)__builtin_amdgcn_exp2f(f), e);
+}
+
+// sqrt(n) and 1/sqrt(n) without a division: hardware reciprocal square root, one Newton step on it, then one
+// residual step on the root itself (sq within 1 ulp; r good to ~1e-15)
+__device__ __forceinline__ void sqrt_rsqrt(double nd, double& sq, double& r) {
+    const double r0 = __builtin_amdgcn_rsq(nd);
+    r = __builtin_fma(0.5 * r0, __builtin_fma(-(nd * r0), r0, 1.0), r0);
+    const double s0 = nd * r;
+    sq = __builtin_fma(__builtin_fma(-s0, s0, nd), 0.5 * r, s0);
+}
+
+// log_q_approx for u = k / sqrt(n) > 24 (Philox mode).  There the get_v iteration's limit can be written down
+// directly: v = C0 u (1 - eps), eps = C1 (C0 u + 1) x, x = exp(-C0 u), C0 = pi/sqrt 6, C1 = 3/pi^2 (the first
+// iterate's own correction changes x by < 1e-8 relative, i.e. the result by < 1e-17), and the closing
+// formula becomes
+//   (LFC - log n + 2 C0 sq) + x (k + (1 + u^2/2)/2) - eps (2 C0 sq + 1).
+// log(n) comes from the host-built table; the x terms are < 1.7e-9 of the result and are evaluated with fused
+// multiply-adds and a 1e-7-accurate exponential.  Against the literal evaluation for u in [24, 70], n up to
+// 6e7: within 6e-16 relative.
+__device__ __forceinline__ double log_q_closed(double kd, double sq, double r, double logn, const LogQConsts& c) {
+    const double u = kd * r;
+    const double x = exp2_filter(u * c.nc0l2e);
+    const double eps = __builtin_fma(c.c1c0, u, c.c1) * x;
+    const double a = __builtin_fma(u * u, 0.25, kd + 0.5);
+    const double t2 = c.c2c0 * sq;
+    const double corr = __builtin_fma(x, a, -__builtin_fma(eps, t2, eps));
+    return ((c.lfc - logn) + t2) + corr;
 }
 
 // log_q_approx, int_part.cc:89-98.
@@ -437,33 +471,14 @@ __device__ inline double log_q_approx(const Tables& t, unsigned long long n, uns
     const double LFC = -0x1.ef8383c50bb74p+0;  // log(pi/sqrt 6) - 1.5 log 2 - log pi
     double sq, u;
     if (FAST) {
-        // sqrt(n) and k / sqrt(n) without a division: hardware reciprocal square root, one Newton step on it,
-        // then one residual step on the root itself (sq is within 1 ulp; u only has to be good to ~1e-15,
-        // it enters through terms of relative weight < 2e-9 and the tier choice)
-        const double nd = (double)(uint32_t)n;
-        const double r0 = __builtin_amdgcn_rsq(nd);
-        const double r = __builtin_fma(0.5 * r0, __builtin_fma(-(nd * r0), r0, 1.0), r0);
-        const double s0 = nd * r;
-        sq = __builtin_fma(__builtin_fma(-s0, s0, nd), 0.5 * r, s0);
+        double r;
+        sqrt_rsqrt((double)(uint32_t)n, sq, r);
         u = (double)(uint32_t)k * r;
+        if (__builtin_expect(u > 24.0, 1))  // logn_pre = logtab[n], loaded by the caller with the other gathers
+            return log_q_closed((double)(uint32_t)k, sq, r, logn_pre, log_q_consts());
     } else {
         sq = sqrt((double)n);
         u = (double)k / sq;  // :92
-    }
-    if (FAST && __builtin_expect(u > 24.0, 1)) {
-        // For u > 24 the iteration's limit can be written down directly: v = C0 u (1 - eps) with
-        // eps = C1 (C0 u + 1) x, x = exp(-C0 u) (the first iterate's own correction changes x by
-        // < 1e-8 relative, i.e. the result by < 1e-17), and the closing formula becomes
-        //   (LFC - log n + 2 C0 sq) + x (k + (1 + u^2/2)/2) - eps (2 C0 sq + 1).
-        // log(n) comes from the host-built table; the x terms are < 1.7e-9 of the result and are evaluated
-        // with fused multiply-adds.  Against the literal evaluation for u in [24, 70], n up to 6e7: within
-        // 6e-16 relative.
-        const double x = exp2_lowprec(u * -0x1.d9af1d38092ecp+0);  // exp(-C0 u) as 2^(-C0 log2(e) u)
-        const double eps = __builtin_fma(C1 * C0, u, C1) * x;
-        const double a = __builtin_fma(u * u, 0.25, (double)(uint32_t)k + 0.5);
-        const double t2 = (2 * C0) * sq;
-        const double corr = __builtin_fma(x, a, -__builtin_fma(eps, t2, eps));
-        return ((LFC - logn_pre) + t2) + corr;  // logn_pre = logtab[n], loaded by the caller with the other gathers
     }
     if (FAST && u > 21.0) {
         double v = u, x, eps, delta;

@@ -68,16 +68,6 @@ __device__ __forceinline__ double tab_at(const double* base, uint32_t idx) {
 constexpr uint32_t kHistStride = 68;  // bytes per k_v row: 64 counters + pad (17 dwords: odd, conflict-free)
 constexpr uint32_t kHandWords = 5;    // v, row begin, degree, own label, pivot label
 
-// 2^t for moderate |t| to ~1e-7 relative: f64 range reduction, v_exp_f32 on the fraction.  The integer part goes
-// through v_cvt_i32_f64 itself (saturating, NaN -> 0), so any finite or infinite t is safe.
-__device__ __forceinline__ double exp2_filter(double t) {
-    const double ti = rint(t);
-    const float f = (float)(t - ti);
-    int e;
-    __asm__("v_cvt_i32_f64 %0, %1" : "=v"(e) : "v"(ti));
-    return ldexp((double)__builtin_amdgcn_exp2f(f), e);
-}
-
 // a double constant held in a vector register pair for the whole kernel (64-bit literals are not encodable
 // and the scalar file is full: without this the hot loop rebuilds them with s_mov pairs at every use)
 #define BISBM_PIN(name, value) \
@@ -153,11 +143,8 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     // constants of the hot step (log_q closed form, accept filter)
     BISBM_PIN(c_l2e, 0x1.71547652b82fep+0);        // log2(e)
     BISBM_PIN(c_tol, 1e-5);                        // accept filter margin
-    BISBM_PIN(c_nc0l2e, -0x1.d9af1d38092ecp+0);    // -(pi/sqrt 6) log2(e)
-    BISBM_PIN(c_c1c0, 0x1.37423899a1558p-2 * 0x1.48552f88091a8p+0);  // (3/pi^2)(pi/sqrt 6)
-    BISBM_PIN(c_c1, 0x1.37423899a1558p-2);         // 3/pi^2
-    BISBM_PIN(c_2c0, 2 * 0x1.48552f88091a8p+0);    // 2 pi/sqrt 6
-    BISBM_PIN(c_lfc, -0x1.ef8383c50bb74p+0);       // log(pi/sqrt 6) - 1.5 log 2 - log pi
+    LogQConsts lqc = log_q_consts();  // log_q closed form
+    __asm__ volatile("" : "+v"(lqc.nc0l2e), "+v"(lqc.c1c0), "+v"(lqc.c1), "+v"(lqc.c2c0), "+v"(lqc.lfc));
     BISBM_PIN(c_576, 576.0);                       // 24^2: tier test k^2 > 576 n
     uint64_t accepted_steps = 0, u_cnt = 0, sweeps_done = 0;
     double entropy_min = INFINITY;  // metropolis_hasting.cc:75
@@ -533,17 +520,9 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                         const double nd = (double)qn, kd = (double)qk2;
                         const bool direct = qn > kQNmax && kd * kd > c_576 * nd;
                         if (__builtin_expect(__builtin_amdgcn_ballot_w64(!direct) == 0, 1)) {  // (lanes repeat mod 4)
-                            const double r0 = __builtin_amdgcn_rsq(nd);
-                            const double rr = __builtin_fma(0.5 * r0, __builtin_fma(-(nd * r0), r0, 1.0), r0);
-                            const double s0 = nd * rr;
-                            const double sq = __builtin_fma(__builtin_fma(-s0, s0, nd), 0.5 * rr, s0);
-                            const double u = kd * rr;
-                            const double x = exp2_filter(u * c_nc0l2e);
-                            const double e1 = __builtin_fma(c_c1c0, u, c_c1) * x;
-                            const double aa = __builtin_fma(u * u, 0.25, kd + 0.5);
-                            const double t2 = c_2c0 * sq;
-                            const double corr = __builtin_fma(x, aa, -__builtin_fma(e1, t2, e1));
-                            lq = ((c_lfc - logn) + t2) + corr;
+                            double sq, rr;
+                            sqrt_rsqrt(nd, sq, rr);
+                            lq = log_q_closed(kd, sq, rr, logn, lqc);
                         } else {
                             lq = log_q<true>(tab, qn, qk, logn);
                         }
