@@ -116,6 +116,9 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
             for (uint32_t i = lane; i < K * D; i += kWave) eta_l[i] = eta_g[i];
         if (lane == 0) *stop_flag = 0;
     }
+    // The stepping wave shares its SIMD with the feeder wave of another chain (four chains per CU): it is the
+    // critical path, so it issues first whenever both have an instruction ready.
+    if (is_main) __builtin_amdgcn_s_setprio(3);
     int mrA = lane < ka ? mr_g[lane] : 0, nrA = lane < ka ? nr_g[lane] : 0;
     int mrB = lane < kb ? mr_g[ka + lane] : 0, nrB = lane < kb ? nr_g[ka + lane] : 0;
     __syncthreads();
@@ -180,7 +183,8 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
             const int odd_mask_l = (lane & 1u) ? -1 : 0;
             const int eta_mask_l = (lane & 4u) ? -1 : 0;                          // lanes 4..7 (mod 8): the eta terms
             const int toff_l = (lane & 4u) ? eoff_l : 1;                          // table index = argument + this
-            const int oth_mask_l = lane < k_oth ? -1 : 0;
+            int oth_mask_l = lane < k_oth ? -1 : 0;
+            __asm__ volatile("" : "+v"(oth_mask_l));  // (opaque: stays an AND with a vector register)
             Feistel order;
             order.init(phx_draw(p.seed, chain_gid, PHX_SWEEP_KEY, 2 * sweeps_total + (TB ? 1 : 0)), n_own);
             const uint32_t n_chunks = (n_own + kWave - 1) / kWave;
@@ -307,7 +311,10 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     // k_v counter of lane's block, row r of m, eta[r][deg] (unconditional reads, idle lanes masked
                     // afterwards: the k_v bytes past k_oth are zero, and the m reads past the quadrant stay inside
                     // the kernel's LDS allocation, see sweep_fast_lds_bytes)
-                    int k = (int)hist8_cur[q * kHistStride + lane];
+                    // (k_v read as a dword + shift: a different instruction from the hot step's byte read, so the
+                    // compiler does not merge the two above the branch between the paths and wait for it there)
+                    const uint32_t kbyte = q * kHistStride + lane;
+                    int k = (int)((((const uint32_t*)hist8_cur)[kbyte >> 2] >> ((kbyte & 3u) * 8u)) & 0xffu);
                     const uint32_t a_rt = mq_at(r_loc, lane);
                     const int32_t m_rt_raw = mq[a_rt];
                     const int32_t m_rt = lane < k_oth ? m_rt_raw : 0;
@@ -461,6 +468,12 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     const int32_t m_rt_raw = mq[a_rt];
                     const int w_piv = mq[mq_at(lane, t_loc)];
                     const int n_r_r = readlane(nr_own, r_loc);
+                    // the two lgamma gathers that only need row r go out now: their latency runs under the proposal
+                    const int32_t m_rt = m_rt_raw & oth_mask_l;  // idle lanes: 0
+                    const uint32_t kk = (uint32_t)k;
+                    const double L1 = tab_at(tab.lg, (uint32_t)(m_rt + 1));
+                    const double L3 = tab_at(tab.lg, (uint32_t)(m_rt + 1) - kk);
+                    __asm__ volatile("" ::: "memory");  // keeps the loads above from being sunk below the r == s test
                     FSTAMP(1);
                     // integer inverse CDF (:627-628): first own block whose running total exceeds x.  Lanes past
                     // k_own hold garbage, but block k_own - 1 always qualifies (its total is m_r[t] > x).
@@ -478,8 +491,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     const int32_t m_st_raw = mq[a_st];
                     const int eta_r = (int)eta_rd(r * D + deg);
                     const int eta_s = (int)eta_rd(s * D + deg);
-                    const int32_t m_rt = m_rt_raw & oth_mask_l;  // idle lanes: 0
-                    const int32_t m_st = m_st_raw & oth_mask_l;
+                    const int32_t m_st = m_st_raw & oth_mask_l;  // idle lanes: 0
                     const int m0r = readlane(mr_own, r_loc);
                     const int m0s = readlane(mr_own, s_loc);
                     const int n_r_s = readlane(nr_own, s_loc);
@@ -492,10 +504,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     const int qk = (n_r_r ^ ((n_r_r ^ n_r_s) & odd_mask_l)) + dq_l;
                     const double tail_lg = tab_at(tab.lg, tail_idx);
                     const double logn = tab_at(tab.logtab, (uint32_t)qn);  // log(n) of the log_q arguments
-                    const uint32_t kk = (uint32_t)k;
-                    const double L1 = tab_at(tab.lg, (uint32_t)(m_rt + 1));
                     const double L2 = tab_at(tab.lg, (uint32_t)(m_st + 1));
-                    const double L3 = tab_at(tab.lg, (uint32_t)(m_rt + 1) - kk);
                     const double L4 = tab_at(tab.lg, (uint32_t)(m_st + 1) + kk);
                     FSTAMP(3);
                     // Hastings sums: on-chip data only, they run while the table gathers are in flight.
@@ -578,11 +587,14 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
             if (!is_main) prepare(0);
             __syncthreads();
             for (uint32_t c = 0; c < n_chunks; ++c) {
-                if (is_main)
+                if (is_main) {
                     run_steps(c);
-                else if (c + 1 < n_chunks)
+                    FSTAMP(9);
+                } else if (c + 1 < n_chunks) {
                     prepare(c + 1);
+                }
                 __syncthreads();
+                if (is_main) FSTAMP(10);  // (diagnostic builds: time spent waiting for the feeder)
             }
         };
         run_phase(std::false_type{});
@@ -667,11 +679,11 @@ hipError_t launch_sweep_fast(const SweepParams& p, size_t /*generic_lds_bytes*/,
         unsigned long long h[16] = {0};
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fast_stamps), sizeof(h));
         const double steps = (double)p.n_chains * (double)(p.duration / p.n) * (double)p.n;
-        static const char* names[9] = {"loop+chunk prologue", "early reads", "proposal", "lds+gather issue", "accu",
-                                       "log_q", "dS butterfly", "accept", "apply"};
+        static const char* names[11] = {"step entry (+ early exits)", "early reads", "proposal", "lds+gather issue", "accu",
+                                        "log_q", "dS butterfly", "accept", "apply", "chunk tail", "barrier wait"};
         double tot = 0;
-        for (int i = 0; i < 9; ++i) tot += (double)h[i];
-        for (int i = 0; i < 9; ++i) fprintf(stderr, "[stamps] %-20s %8.1f cyc/step\n", names[i], (double)h[i] / steps);
+        for (int i = 0; i < 11; ++i) tot += (double)h[i];
+        for (int i = 0; i < 11; ++i) fprintf(stderr, "[stamps] %-28s %8.2f ticks/step\n", names[i], (double)h[i] / steps);
         fprintf(stderr, "[stamps] %-20s %8.1f cyc/step\n", "total", tot / steps);
         unsigned long long z[16] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fast_stamps), z, sizeof(z));
