@@ -25,9 +25,17 @@
 // LDS; m_r / n_r in registers (lane i <-> block i of each type).  dS and the Hastings sums are DPP
 // butterflies; the four log_q values are one SIMT evaluation; the four uniforms of a step come from one
 // Philox evaluation per 64 steps per lane; apply_mcmc_moves writes values it already holds.
-// No generic pointers (flat loads wait on vmcnt AND lgkmcnt), no workgroup barriers on the step path,
-// rare cases (rows longer than 64, r == s, cross-type targets) run the same straight-line code or a cold
-// side path.  Diagnostic hooks (BISBM_STAMPS, BISBM_ABLATE) are compiled out of the product build.
+//
+// A lone wave per SIMD pays one issue slot (~4.3 cycles) for EVERY instruction and 25-40 cycles for every
+// vector->scalar->vector crossing (tools/probe/issue_latency.hip), so the step exists twice:
+//   * the hot step: 1 <= deg <= 64, target drawn from column m[.][t], T > 0, closed-form log_q tier.
+//     Straight-line code, one test for "rare" at the top, r == s leaves right after the proposal, one tier
+//     test, one crossing for the accept decision; lane patterns are bit arithmetic on per-lane constant
+//     masks, the constants of the closed forms sit in vector registers (the scalar file is full);
+//   * the general step: the literal definition (uniform random targets, empty and over-long rows, a
+//     single own block, T = 0, every log_q tier).  The hot step hands over before it writes anything.
+// No generic pointers (flat loads wait on vmcnt AND lgkmcnt), no workgroup barriers on the step path.
+// Diagnostic hooks (BISBM_STAMPS, BISBM_ABLATE) are compiled out of the product build.
 #include "bisbm_kernels.hpp"
 
 #include <cstdio>

@@ -10,8 +10,9 @@
  *                   reference outputs recorded in SURVEY.md.
  *   ORC_RNG_PHILOX  the production definition the HIP kernels implement: the same Markov chain
  *                   (same proposal distribution, same dS, same accept rule, same bookkeeping)
- *                   driven by Philox4x32-10 counters, a Feistel visit order per sweep, an integer
- *                   inverse-CDF draw, and a fixed 64-leaf butterfly for the four FP64 sums.
+ *                   driven by Philox4x32-10 counters, a Feistel visit order per sweep and type
+ *                   (all type-a nodes, then all type-b nodes), an integer inverse-CDF draw, and a
+ *                   fixed 64-leaf butterfly for the three FP64 sums (dS, accu0, accu1).
  *                   The GPU must match this mode bit-for-bit on integers.
  *
  * Paths cited below are relative to /root/reference/src.
