@@ -64,6 +64,8 @@ ABI = {
     "bisbm_marginals_reset": (C.c_int, [C.c_void_p]),
     "bisbm_marginals_get": (C.c_int, [C.c_void_p, _u32p]),
     "bisbm_get_ka_kb": (C.c_int, [C.c_void_p, _u32p, _u32p]),
+    "bisbm_agg_merge": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "bisbm_agg_merge_total": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "bisbm_get_sizes": (C.c_int, [C.c_void_p, _u64p, _u64p, _u32p, _u32p]),
     "bisbm_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bisbm_last_sweep_timing": (C.c_int, [C.c_void_p, _f64p, _u64p]),
@@ -320,6 +322,23 @@ class BlockModel:
         s = stream or sys.stderr
         s.write("(Ka, Kb) = (%d, %d) \n" % (self.KA, self.KB))
         s.write("entropy: %s\n" % _fmt_g6(self.entropy()[0]))
+
+    # -- agglomerative merges between anneals (blockmodel.cc:109-271)
+    def _refresh_k(self):
+        ka, kb = C.c_uint32(), C.c_uint32()
+        self._check(self._L.bisbm_get_ka_kb(self._h, C.byref(ka), C.byref(kb)))
+        self.KA, self.KB = ka.value, kb.value
+        self.K = self.KA + self.KB
+
+    def agg_merge(self, diff_a, diff_b=None, nm=10):
+        """``agg_merge(engine, diff_a, diff_b, nm)`` (blockmodel.cc:109-206) or, with ``diff_b=None``,
+        ``agg_merge(engine, diff, nm)`` (:208-271), in every chain."""
+        if diff_b is None:
+            rc = self._L.bisbm_agg_merge_total(self._h, int(diff_a), int(nm))
+        else:
+            rc = self._L.bisbm_agg_merge(self._h, int(diff_a), int(diff_b), int(nm))
+        self._check(rc)
+        self._refresh_k()
 
     def get_KA(self):
         return self.KA

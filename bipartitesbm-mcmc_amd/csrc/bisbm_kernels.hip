@@ -821,6 +821,48 @@ hipError_t launch_labels_broadcast(const uint32_t* src, uint8_t* labels, size_t 
     return hipGetLastError();
 }
 
+// ---- relabelling after block merges (apply_block_moves, blockmodel.cc:567-611) ----
+// first[chain][l] = lowest node id whose label maps to l under map1 (the order in which the reference compacts)
+__global__ void merge_first_kernel(const uint8_t* labels, size_t label_stride, uint32_t n, const uint8_t* map1,
+                                   uint32_t* first) {
+    __shared__ uint32_t lfirst[256];
+    __shared__ uint8_t lmap[256];
+    const uint32_t chain = blockIdx.y;
+    lfirst[threadIdx.x] = 0xffffffffu;
+    lmap[threadIdx.x] = map1[(size_t)chain * 256 + threadIdx.x];
+    __syncthreads();
+    const uint8_t* lab = labels + (size_t)chain * label_stride;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x)
+        atomicMin(&lfirst[lmap[lab[v]]], v);
+    __syncthreads();
+    if (lfirst[threadIdx.x] != 0xffffffffu) atomicMin(&first[(size_t)chain * 256 + threadIdx.x], lfirst[threadIdx.x]);
+}
+
+__global__ void merge_relabel_kernel(uint8_t* labels, size_t label_stride, uint32_t n, const uint8_t* fmap) {
+    __shared__ uint8_t lmap[256];
+    const uint32_t chain = blockIdx.y;
+    lmap[threadIdx.x] = fmap[(size_t)chain * 256 + threadIdx.x];
+    __syncthreads();
+    uint8_t* lab = labels + (size_t)chain * label_stride;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) lab[v] = lmap[lab[v]];
+}
+
+hipError_t launch_merge_first(const uint8_t* labels, size_t label_stride, uint32_t n, uint32_t n_chains,
+                              const uint8_t* map1, uint32_t* first, hipStream_t stream) {
+    const uint32_t tiles = std::min<uint32_t>((n + 256 * 16 - 1) / (256 * 16), 1024u);
+    hipLaunchKernelGGL(merge_first_kernel, dim3(tiles ? tiles : 1, n_chains), dim3(256), 0, stream, labels, label_stride, n,
+                       map1, first);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_relabel(uint8_t* labels, size_t label_stride, uint32_t n, uint32_t n_chains, const uint8_t* fmap,
+                                hipStream_t stream) {
+    const uint32_t tiles = std::min<uint32_t>((n + 256 * 16 - 1) / (256 * 16), 1024u);
+    hipLaunchKernelGGL(merge_relabel_kernel, dim3(tiles ? tiles : 1, n_chains), dim3(256), 0, stream, labels, label_stride, n,
+                       fmap);
+    return hipGetLastError();
+}
+
 hipError_t launch_labels_widen(const uint8_t* labels, uint32_t* dst, uint32_t n, hipStream_t stream) {
     const uint32_t tiles = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
     hipLaunchKernelGGL(labels_widen_kernel, dim3(tiles ? tiles : 1), dim3(256), 0, stream, labels, dst, n);

@@ -20,7 +20,7 @@ struct ChainScalars {
     uint32_t shuffle_epoch;  // Philox counter: shuffle_bisbm calls so far
     uint32_t engine_idx;     // std::mt19937 positions (compat mode)
     uint32_t gen_idx;
-    uint32_t pad_;
+    uint32_t merge_epoch;  // Philox counter: proposal rounds of agg_merge so far
 };
 
 struct SweepParams {
@@ -131,6 +131,11 @@ hipError_t launch_state_build(const BuildParams& p, hipStream_t stream);
 hipError_t launch_labels_broadcast(const uint32_t* src, uint8_t* labels, size_t label_stride, uint32_t n,
                                    uint32_t first_chain, uint32_t n_chains, hipStream_t stream);
 hipError_t launch_labels_widen(const uint8_t* labels, uint32_t* dst, uint32_t n, hipStream_t stream);
+// relabelling after block merges: map1 / fmap are [n_chains][256] byte tables, first is [n_chains][256] (preset to ~0)
+hipError_t launch_merge_first(const uint8_t* labels, size_t label_stride, uint32_t n, uint32_t n_chains,
+                              const uint8_t* map1, uint32_t* first, hipStream_t stream);
+hipError_t launch_merge_relabel(uint8_t* labels, size_t label_stride, uint32_t n, uint32_t n_chains, const uint8_t* fmap,
+                                hipStream_t stream);
 hipError_t launch_shuffle(const ShuffleParams& p, int rng_mode, hipStream_t stream);
 hipError_t launch_entropy(const EntropyParams& p, hipStream_t stream);
 hipError_t launch_marginals(const MarginalParams& p, hipStream_t stream);

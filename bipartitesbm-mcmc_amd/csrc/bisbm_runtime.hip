@@ -14,6 +14,10 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <queue>
+#include <random>
+#include <set>
+#include <sstream>
 #include <string>
 #include <thread>
 #include <utility>
@@ -809,3 +813,412 @@ int bisbm_debug_log_q(bisbm_handle h, const int32_t* n, const int32_t* k, size_t
 }
 
 }  // extern "C"
+
+
+// ---------------------------------------------------------------------------------------------
+// Agglomerative merges between anneals: blockmodel_t::agg_merge x2, compute_b_adj_list,
+// compute_dS(block_move_t), apply_block_moves, single_block_change (blockmodel.cc:109-288,335-372,567-611,
+// 639-669).  K-scale work on the host, as in the reference, one chain after the other; the device supplies the
+// first node of every label (the order in which the reference renumbers blocks) and applies the final relabelling
+// to all chains at once, then rebuilds the block state.  Between proposal rounds the block matrix is merged on
+// the host (m is additive over blocks), which is what the reference's full rebuild computes.
+// mt19937-compat mode draws with libstdc++'s own std::mt19937 / uniform_real_distribution / discrete_distribution
+// restored from the chain's device-side generator state -- the reference's draw sequence by construction.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+void philox_host(uint64_t seed, uint32_t chain, uint32_t purpose, uint64_t idx, uint32_t out[4]) {
+    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = chain, c3 = purpose;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+double u53_host(uint32_t hi, uint32_t lo) { return (double)((((uint64_t)hi << 32) | lo) >> 11) * 0x1.0p-53; }
+
+constexpr uint32_t kPhxMergeA = 4, kPhxMergeB = 5;
+
+struct MergeChain {
+    // block state in the current numbering
+    size_t K = 0, ka = 0, kb = 0, na = 0;
+    std::vector<int> M;            // K x K, symmetric
+    std::vector<int> m_r;          // row sums
+    std::vector<uint32_t> first;   // lowest node id of each block
+    std::vector<uint8_t> cmap;     // original label -> current label (256 entries, 0xff = gone)
+    // randomness
+    bool compat = false;
+    std::mt19937 engine, gen;
+    std::uniform_real_distribution<> random_real;  // blockmodel.hh:16
+    uint64_t seed = 0;
+    uint32_t chain_gid = 0, epoch = 0;
+    double epsilon = 0;
+    const std::vector<double>* lg = nullptr;
+
+    int at(size_t i, size_t j) const { return M[i * K + j]; }
+    double lgamma_fast(long long x) const { return (*lg)[(size_t)x]; }  // table covers 2E+1 (bisbm_create)
+
+    // single_block_change, blockmodel.cc:639-669 (ctr: index of the proposal inside the round, Philox mode)
+    std::pair<size_t, size_t> propose(size_t src, uint64_t ctr) {
+        if ((ka == 1 && src < ka) || (kb == 1 && src >= ka)) return {src, src};
+        std::vector<size_t> badj;  // compute_b_adj_list, :274-288
+        for (size_t t = 0; t < K; ++t)
+            if (at(src, t) > 0) badj.push_back(t);
+        size_t target;
+        if (compat) {
+            if (badj.empty()) {
+                target = size_t(random_real(engine) * K);
+            } else {
+                const size_t t = badj[size_t(random_real(engine) * badj.size())];
+                const double R_t = epsilon * K / (m_r[t] + epsilon * K);
+                if (random_real(engine) < R_t) {
+                    target = size_t(random_real(engine) * K);
+                } else {
+                    std::discrete_distribution<size_t> d(M.begin() + t * K, M.begin() + (t + 1) * K);
+                    target = d(gen);  // drawn with `gen`, :656-657
+                }
+            }
+        } else {
+            uint32_t A[4], B[4];
+            const uint64_t idx = ((uint64_t)epoch << 32) | ctr;
+            philox_host(seed, chain_gid, kPhxMergeA, idx, A);
+            philox_host(seed, chain_gid, kPhxMergeB, idx, B);
+            const double u0 = u53_host(A[0], A[1]), u1 = u53_host(A[2], A[3]), u2 = u53_host(B[0], B[1]);
+            if (badj.empty()) {
+                target = std::min(size_t(u0 * (double)K), K - 1);
+            } else {
+                const size_t t = badj[std::min(size_t(u0 * (double)badj.size()), badj.size() - 1)];
+                if (u1 * (m_r[t] + epsilon * (double)K) < epsilon * (double)K) {
+                    target = std::min(size_t(u2 * (double)K), K - 1);
+                } else {  // integer inverse CDF over row m[t][.]
+                    const long long tot = m_r[t];
+                    const long long x = std::min((long long)(u2 * (double)tot), tot - 1);
+                    long long cum = 0;
+                    target = K - 1;
+                    for (size_t c = 0; c < K; ++c) {
+                        cum += at(t, c);
+                        if (cum > x) {
+                            target = c;
+                            break;
+                        }
+                    }
+                }
+            }
+        }
+        return src > target ? std::make_pair(src, target) : std::make_pair(target, src);  // higher index merges into lower
+    }
+
+    // compute_dS(const block_move_t&), blockmodel.cc:335-372
+    double merge_dS(size_t r, size_t s) const {
+        if (r == s || (r < ka && s >= ka) || (r >= ka && s < ka)) return std::numeric_limits<double>::infinity();
+        double entropy0 = 0., entropy1 = 0.;
+        for (size_t idx = 0; idx < K; ++idx) {
+            const bool opposite = r < ka ? idx >= ka : idx < ka;
+            if (opposite && m_r[idx] != 0) {
+                entropy0 -= lgamma_fast(at(r, idx) + 1);
+                entropy0 -= lgamma_fast(at(s, idx) + 1);
+                entropy1 -= lgamma_fast(at(s, idx) + at(r, idx) + 1);
+            }
+        }
+        entropy0 -= -lgamma_fast(m_r[r] + 1);
+        entropy0 -= -lgamma_fast(m_r[s] + 1);
+        entropy1 -= -lgamma_fast(m_r[r] + m_r[s] + 1);
+        return entropy1 - entropy0;
+    }
+
+    using HeapItem = std::pair<double, size_t>;
+    using Heap = std::priority_queue<HeapItem, std::vector<HeapItem>, std::greater<>>;
+
+    // one proposal round: nm proposals for every block of [first_block, first_block + count), unique (source, target)
+    // pairs keyed by dS (:147-159)
+    void propose_round(size_t first_block, size_t count, int nm, std::vector<std::pair<size_t, size_t>>& moves, Heap& q) {
+        std::set<std::pair<size_t, size_t>> seen;
+        moves.clear();
+        q = Heap();
+        uint64_t ctr = 0;
+        for (size_t b = first_block; b < first_block + count; ++b)
+            for (int i = 0; i < nm; ++i) {
+                const auto mv = propose(b, ctr++);
+                if (seen.insert(mv).second) {
+                    q.push({merge_dS(mv.first, mv.second), moves.size()});
+                    moves.push_back(mv);
+                }
+            }
+        ++epoch;
+    }
+
+    // bookkeeping of one accepted merge (:172-184)
+    static void accept(std::set<size_t>& touched, std::vector<std::set<size_t>>& groups, size_t src, size_t tgt) {
+        if (touched.count(src) == 0 && touched.count(tgt) == 0) {
+            groups.push_back({src, tgt});
+        } else {
+            for (auto& g : groups)
+                if (g.count(tgt) > 0 || g.count(src) > 0) {
+                    g.insert({src, tgt});
+                    break;
+                }
+        }
+        touched.insert({src, tgt});
+    }
+
+    // apply_block_moves (:567-611) on the block level: merge the groups, renumber the blocks in the order of their
+    // first node.  false = the reference's sanity check would fail.
+    bool apply(const std::set<size_t>& touched, const std::vector<std::set<size_t>>& groups) {
+        std::vector<size_t> to(K);
+        for (size_t b = 0; b < K; ++b) {
+            size_t mb = b;
+            if (touched.count(mb) > 0)
+                for (auto const& g : groups)
+                    if (g.count(mb) > 0) mb = *g.begin();
+            to[b] = mb;
+        }
+        std::vector<uint32_t> nfirst(K, 0xffffffffu);
+        for (size_t b = 0; b < K; ++b) nfirst[to[b]] = std::min(nfirst[to[b]], first[b]);
+        std::vector<size_t> order;  // surviving blocks by first node
+        for (size_t b = 0; b < K; ++b)
+            if (nfirst[b] != 0xffffffffu) order.push_back(b);
+        std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return nfirst[x] < nfirst[y]; });
+        std::vector<size_t> n2o(K, (size_t)-1);
+        for (size_t i = 0; i < order.size(); ++i) n2o[order[i]] = i;
+        const size_t nK = order.size();
+        size_t nka = 0;
+        for (size_t i = 0; i < nK; ++i) nka += nfirst[order[i]] < na;
+        // labels of type-a nodes must occupy [0, nka): first nodes are sorted and type-a ids come first
+        std::vector<int> nM(nK * nK, 0);
+        for (size_t i = 0; i < K; ++i) {
+            if (n2o[to[i]] == (size_t)-1) continue;  // empty block
+            for (size_t j = 0; j < K; ++j)
+                if (n2o[to[j]] != (size_t)-1) nM[n2o[to[i]] * nK + n2o[to[j]]] += at(i, j);
+        }
+        for (auto& c : cmap)
+            if (c != 0xff) c = n2o[to[c]] == (size_t)-1 ? 0xff : (uint8_t)n2o[to[c]];
+        std::vector<uint32_t> f2(nK);
+        for (size_t i = 0; i < nK; ++i) f2[i] = nfirst[order[i]];
+        first.swap(f2);
+        M.swap(nM);
+        K = nK;
+        ka = nka;
+        kb = nK - nka;
+        m_r.assign(K, 0);
+        for (size_t i = 0; i < K; ++i)
+            for (size_t j = 0; j < K; ++j) m_r[i] += at(i, j);
+        return ka >= 1 && kb >= 1;
+    }
+
+    // agg_merge(engine, diff_a, diff_b, nm), :109-206.  0 ok, -1 sanity, -3 cannot make progress
+    int agg_merge(int diff_a, int diff_b, int nm) {
+        for (int depth = 0; depth < 10000; ++depth) {
+            if (diff_a + diff_b == 0) return 0;
+            size_t first_block, count;
+            if (diff_a > 0 && diff_b == 0)
+                first_block = 0, count = ka;
+            else if (diff_a == 0 && diff_b > 0)
+                first_block = ka, count = kb;
+            else
+                first_block = 0, count = K;
+            std::vector<std::pair<size_t, size_t>> moves;
+            Heap q;
+            propose_round(first_block, count, nm, moves, q);
+            std::set<size_t> touched;
+            std::vector<std::set<size_t>> groups;
+            bool again = false;
+            size_t merged = 0;
+            while (diff_a + diff_b != 0 && !q.empty()) {
+                if (q.top().first == std::numeric_limits<double>::infinity()) {  // :163-168: apply, then start over
+                    again = true;
+                    break;
+                }
+                const auto mv = moves[q.top().second];
+                int* budget = (mv.first < ka && diff_a != 0) ? &diff_a : ((mv.first >= ka && diff_b != 0) ? &diff_b : nullptr);
+                if (budget && !(touched.count(mv.first) > 0 && touched.count(mv.second) > 0)) {
+                    *budget -= 1;
+                    accept(touched, groups, mv.first, mv.second);
+                    ++merged;
+                }
+                q.pop();
+            }
+            if (!apply(touched, groups)) return -1;
+            if (!again) return 0;
+            // the reference recurses without end when the remaining budget asks for merges in a type that is down to
+            // one block
+            if (merged == 0 && !((diff_a > 0 && ka > 1) || (diff_b > 0 && kb > 1))) return -3;
+        }
+        return -3;
+    }
+
+    // agg_merge(engine, diff, nm), :208-271
+    int agg_merge_total(int diff, int nm) {
+        if (diff == 0) return 0;
+        const int DIFF = diff;
+        std::set<size_t> touched;
+        std::vector<std::set<size_t>> groups;
+        std::vector<std::pair<size_t, size_t>> moves;
+        Heap q;
+        bool minS = true;
+        for (int rounds = 0; minS; ++rounds) {
+            if (rounds >= 10000) return -3;
+            groups.clear();
+            touched.clear();
+            propose_round(0, K, nm, moves, q);
+            while (diff != 0 && !q.empty()) {
+                const auto mv = moves[q.top().second];
+                if (!(touched.count(mv.first) > 0 && touched.count(mv.second) > 0)) {
+                    diff -= 1;
+                    accept(touched, groups, mv.first, mv.second);
+                }
+                minS = q.top().first == std::numeric_limits<double>::infinity();
+                q.pop();
+            }
+            diff = DIFF;
+        }
+        return apply(touched, groups) ? 0 : -1;
+    }
+};
+
+// which: 0 = agg_merge(diff_a, diff_b, nm), 1 = agg_merge(diff, nm)
+int run_merges(bisbm_engine* h, int which, int diff_a, int diff_b, int nm) {
+    if (!h->state_ready) return fail(h, BISBM_ERR_STATE, "call bisbm_init or bisbm_shuffle before bisbm_agg_merge");
+    if (diff_a < 0 || diff_b < 0)
+        return fail(h, BISBM_ERR_UNSUPPORTED,
+                    "negative diff asks for agg_split (blockmodel.cc:505-565), which reads out of range in the reference "
+                    "and is not provided");
+    if (nm < 1) return fail(h, BISBM_ERR_INVALID_ARG, "nm must be >= 1");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t C = h->n_chains, K0 = h->K, ka0 = h->ka, kb0 = h->kb;
+
+    // first node of every label, all chains
+    uint8_t* d_map = nullptr;
+    uint32_t* d_first = nullptr;
+    HIPCHK(h, dalloc(&d_map, C * 256));
+    HIPCHK(h, dalloc(&d_first, C * 256));
+    std::vector<uint8_t> ident(C * 256);
+    for (size_t i = 0; i < ident.size(); ++i) ident[i] = (uint8_t)(i & 255);
+    auto cleanup = [&]() {
+        (void)hipFree(d_map);
+        (void)hipFree(d_first);
+    };
+#define MCHK(expr)                                                                                     \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            cleanup();                                                                                 \
+            return fail(h, BISBM_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));                     \
+        }                                                                                              \
+    } while (0)
+    MCHK(hipMemcpy(d_map, ident.data(), ident.size(), hipMemcpyHostToDevice));
+    MCHK(hipMemset(d_first, 0xff, sizeof(uint32_t) * C * 256));
+    MCHK(launch_merge_first(h->d_labels, h->label_stride, (uint32_t)h->n, h->n_chains, d_map, d_first, h->stream));
+    MCHK(hipStreamSynchronize(h->stream));
+    std::vector<uint32_t> first(C * 256);
+    MCHK(hipMemcpy(first.data(), d_first, sizeof(uint32_t) * first.size(), hipMemcpyDeviceToHost));
+    std::vector<int32_t> quad(C * ka0 * kb0);
+    MCHK(hipMemcpy(quad.data(), h->d_m, sizeof(int32_t) * quad.size(), hipMemcpyDeviceToHost));
+    std::vector<ChainScalars> sc(C);
+    MCHK(hipMemcpy(sc.data(), h->d_scalars, sizeof(ChainScalars) * C, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> mt_e, mt_g;
+    const bool compat = h->rng_mode == BISBM_RNG_MT19937_COMPAT;
+    if (compat) {
+        mt_e.resize(C * 624);
+        mt_g.resize(C * 624);
+        MCHK(hipMemcpy(mt_e.data(), h->d_mt_engine, sizeof(uint32_t) * mt_e.size(), hipMemcpyDeviceToHost));
+        MCHK(hipMemcpy(mt_g.data(), h->d_mt_gen, sizeof(uint32_t) * mt_g.size(), hipMemcpyDeviceToHost));
+    }
+    auto load_mt = [](std::mt19937& g, const uint32_t* st, uint32_t pos) {  // libstdc++ textual state: 624 words, position
+        std::stringstream ss;
+        for (int i = 0; i < 624; ++i) ss << st[i] << ' ';
+        ss << pos;
+        ss >> g;
+    };
+    auto store_mt = [](const std::mt19937& g, uint32_t* st, uint32_t& pos) {
+        std::stringstream ss;
+        ss << g;
+        for (int i = 0; i < 624; ++i) ss >> st[i];
+        ss >> pos;
+    };
+
+    std::vector<uint8_t> fmap(C * 256, 0);
+    size_t nka = 0, nkb = 0;
+    for (size_t c = 0; c < C; ++c) {
+        MergeChain mc;
+        mc.K = K0, mc.ka = ka0, mc.kb = kb0, mc.na = (size_t)h->na;
+        mc.M.assign(K0 * K0, 0);
+        for (size_t a = 0; a < ka0; ++a)
+            for (size_t b = 0; b < kb0; ++b) {
+                const int v = quad[(c * ka0 + a) * kb0 + b];
+                mc.M[a * K0 + ka0 + b] = v;
+                mc.M[(ka0 + b) * K0 + a] = v;
+            }
+        mc.m_r.assign(K0, 0);
+        for (size_t i = 0; i < K0; ++i)
+            for (size_t j = 0; j < K0; ++j) mc.m_r[i] += mc.M[i * K0 + j];
+        mc.first.assign(first.begin() + c * 256, first.begin() + c * 256 + K0);
+        mc.cmap.assign(256, 0xff);
+        for (size_t i = 0; i < K0; ++i) mc.cmap[i] = (uint8_t)i;
+        mc.compat = compat;
+        mc.seed = h->seed;
+        mc.chain_gid = h->first_chain_id + (uint32_t)c;
+        mc.epoch = sc[c].merge_epoch;
+        mc.epsilon = h->epsilon;
+        mc.lg = &h->tab->lg;
+        if (compat) {
+            load_mt(mc.engine, &mt_e[c * 624], sc[c].engine_idx);
+            load_mt(mc.gen, &mt_g[c * 624], sc[c].gen_idx);
+        }
+        // (the reference renumbers by first appearance on every apply_block_moves, also when nothing merged)
+        const int rc = which == 0 ? mc.agg_merge(diff_a, diff_b, nm) : mc.agg_merge_total(diff_a, nm);
+        if (rc != 0) {
+            cleanup();
+            return fail(h, BISBM_ERR_STATE,
+                        rc == -3 ? "chain %zu: agg_merge cannot reach the requested block counts (the reference would recurse without end)"
+                                 : "chain %zu: block renumbering inconsistent (the reference's sanity check, blockmodel.cc:605-609)",
+                        c);
+        }
+        if (c == 0) nka = mc.ka, nkb = mc.kb;
+        if (mc.ka != nka || mc.kb != nkb) {
+            cleanup();
+            return fail(h, BISBM_ERR_STATE,
+                        "chains ended with different block counts (chain 0: %zu+%zu, chain %zu: %zu+%zu); one (Ka,Kb) per handle",
+                        nka, nkb, c, mc.ka, mc.kb);
+        }
+        for (size_t i = 0; i < 256; ++i) fmap[c * 256 + i] = mc.cmap[i] == 0xff ? 0 : mc.cmap[i];
+        sc[c].merge_epoch = mc.epoch;
+        if (compat) {
+            store_mt(mc.engine, &mt_e[c * 624], sc[c].engine_idx);
+            store_mt(mc.gen, &mt_g[c * 624], sc[c].gen_idx);
+        }
+    }
+    MCHK(hipMemcpy(d_map, fmap.data(), fmap.size(), hipMemcpyHostToDevice));
+    MCHK(launch_merge_relabel(h->d_labels, h->label_stride, (uint32_t)h->n, h->n_chains, d_map, h->stream));
+    MCHK(hipMemcpy(h->d_scalars, sc.data(), sizeof(ChainScalars) * C, hipMemcpyHostToDevice));
+    if (compat) {
+        MCHK(hipMemcpy(h->d_mt_engine, mt_e.data(), sizeof(uint32_t) * mt_e.size(), hipMemcpyHostToDevice));
+        MCHK(hipMemcpy(h->d_mt_gen, mt_g.data(), sizeof(uint32_t) * mt_g.size(), hipMemcpyHostToDevice));
+    }
+    MCHK(hipStreamSynchronize(h->stream));
+#undef MCHK
+    cleanup();
+    h->ka = (uint32_t)nka;
+    h->kb = (uint32_t)nkb;
+    h->K = h->ka + h->kb;
+    return rebuild_state(h);  // init_bisbm() at the end of apply_block_moves (:610)
+}
+
+}  // namespace
+
+int bisbm_agg_merge(bisbm_handle h, int diff_a, int diff_b, int nm) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    return run_merges(h, 0, diff_a, diff_b, nm);
+}
+
+int bisbm_agg_merge_total(bisbm_handle h, int diff, int nm) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    return run_merges(h, 1, diff, 0, nm);
+}

@@ -97,6 +97,32 @@ inline double constant_schedule(size_t, float_vec_t kw) noexcept { return kw[0];
 inline double abrupt_cool_schedule(size_t t, float_vec_t kw) noexcept { return t < kw[0] ? 1. : 0.; }
 using schedule_fn = double (*)(size_t, float_vec_t);
 
+// The stage plan of the merge drivers, support/util.hh:99-145: the side with the larger drop goes down geometrically
+// (floor(start / ratio^i) until <= end), the other side gets the same number of points with the ratio
+// pow(start / end [integer division], 1 / (n - 1)).
+inline std::pair<std::vector<int>, std::vector<int>> geospace(long start_a_in, long end_a_in, long start_b_in,
+                                                              long end_b_in, double ratio) {
+    if (ratio <= 1.) return {std::vector<int>{0}, std::vector<int>{0}};
+    int start_a = (int)start_a_in, end_a = (int)end_a_in, start_b = (int)start_b_in, end_b = (int)end_b_in;
+    const bool reverse = start_a - end_a < start_b - end_b;
+    if (reverse) {
+        std::swap(start_a, start_b);
+        std::swap(end_a, end_b);
+    }
+    std::vector<int> ga, gb;
+    int d = start_a;
+    for (size_t i = 1; d > end_a; ++i) {
+        ga.push_back(d);
+        d = (int)std::floor(start_a / std::pow(ratio, (double)i));
+    }
+    ga.push_back(end_a);
+    const size_t n = ga.size();
+    const double r_ = std::pow((double)(start_b / end_b), 1. / (double)(n - 1));
+    for (size_t idx = 0; idx + 1 < n; ++idx) gb.push_back((int)std::floor(start_b / std::pow(r_, (double)idx)));
+    gb.push_back(end_b);
+    return reverse ? std::make_pair(gb, ga) : std::make_pair(ga, gb);
+}
+
 struct engine_options {  // what the reference does not have: chains, device, RNG definition
     uint32_t n_chains = 1;
     uint32_t first_chain_id = 0;
@@ -137,6 +163,18 @@ public:
         check(bisbm_get_memberships(h_, chain, memberships_.data()));
         return &memberships_;
     }
+    // blockmodel.cc:109-206 and :208-271 (call sites mcmc_main.cc:365,385,429,434,446); the engine lives in the
+    // library.  Negative diffs (agg_split) throw: not provided, see include/bisbm.h.
+    void agg_merge(std::mt19937& /*engine*/, int diff_a, int diff_b, int nm) { agg_merge(diff_a, diff_b, nm); }
+    void agg_merge(std::mt19937& /*engine*/, int diff, int nm) { agg_merge(diff, nm); }
+    void agg_merge(int diff_a, int diff_b, int nm) {
+        check(bisbm_agg_merge(h_, diff_a, diff_b, nm));
+        refresh_k();
+    }
+    void agg_merge(int diff, int nm) {
+        check(bisbm_agg_merge_total(h_, diff, nm));
+        refresh_k();
+    }
     size_t get_KA() const noexcept { return KA_; }
     size_t get_KB() const noexcept { return KB_; }
     int get_num_edges() const {
@@ -165,6 +203,12 @@ public:
 private:
     void check(int rc) const {
         if (rc != BISBM_OK) throw std::runtime_error(std::string("bisbm: ") + bisbm_last_error(h_));
+    }
+    void refresh_k() {
+        uint32_t ka = 0, kb = 0;
+        check(bisbm_get_ka_kb(h_, &ka, &kb));
+        KA_ = ka;
+        KB_ = kb;
     }
     bisbm_handle h_ = nullptr;
     size_t KA_, KB_, n_ = 0;

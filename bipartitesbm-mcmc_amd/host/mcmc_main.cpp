@@ -5,9 +5,12 @@
 // newline), "acceptance ratio" and summary() on clog (:483-485).  Boost.program_options is replaced by a
 // small parser with the same surface (long/short names, `--opt=value`, multitoken options).
 // Extra flags: --chains, --device, --rng {mt19937-compat,philox}, --gen_seed.
-// Not in this build: the agglomerative merge/split drivers (:350-451; SURVEY section 8 "next" f2) -- the
-// flags are parsed and the program says so instead of silently doing something else.
+// The agglomerative drivers (:349-451) run through bisbm_agg_merge; block counts are limited to 256 by the label
+// format, so --merge (one block per node to start with) is for graphs of at most 256 nodes.  Splits
+// (negative diffs, agg_split) are not provided: the library reports it.
 #include <chrono>
+#include <cmath>
+#include <numeric>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -141,8 +144,8 @@ void print_help(const char* argv0) {
                  "  -x [ --steps_await ] arg (=1000)      Stop after x steps without a new minimum.\n"
                  "  -E [ --epsilon ] arg (=1)             epsilon of the smart proposal.\n"
                  "  -r [ --randomize ]                    Randomize initial block state.\n"
-                 "  -g [ --merge ]                        Agglomerative merges (not in this build).\n"
-                 "  -u [ --nature ]                       Agglomerative merges, natural start (not in this build).\n"
+                 "  -g [ --merge ]                        Start from one block per node and merge down to -z KA KB.\n"
+                 "  -u [ --nature ]                       With --merge: merge until a type has fewer than sqrt(2E)/2 blocks.\n"
                  "  -d [ --seed ] arg                     Seed of the mt19937 engine (clock if absent).\n"
                  "  -h [ --help ]                         Produce this help message.\n"
                  "Engine:\n"
@@ -357,12 +360,6 @@ int main(int argc, char const* argv[]) {
     }
     kb -= ka;
     ka += 1;
-    if (merge || nature || ka != KA || kb != KB) {
-        std::cerr << "This build runs the fixed-(KA,KB) sweep path (mcmc_main.cc:452-486); the agglomerative merge/split "
-                     "drivers (mcmc_main.cc:350-451) are not part of it yet.\n";
-        return 2;
-    }
-
     engine_options opt;
     opt.n_chains = (uint32_t)std::strtoul(single("chains", "1").c_str(), nullptr, 10);
     opt.device = std::atoi(single("device", "0").c_str());
@@ -374,6 +371,90 @@ int main(int argc, char const* argv[]) {
     opt.rng_mode = rng == "philox" ? BISBM_RNG_PHILOX : BISBM_RNG_MT19937_COMPAT;
     opt.seed = seed;
     opt.gen_seed = count("gen_seed") ? std::strtoull(single("gen_seed", "0").c_str(), nullptr, 10) : seed + 1;
+
+    // ---- agglomerative drivers, mcmc_main.cc:349-451 ----
+    const double sigma = 1.01;  // :349
+    const float_vec_t agg_merge_kwargs(1, 0.f);
+    auto print_best = [&](blockmodel_t& blockmodel, bool with_k) {
+        uint32_t best = 0;
+        if (opt.n_chains > 1) {
+            const std::vector<double> dl = blockmodel.entropy_all();
+            for (uint32_t c = 1; c < opt.n_chains; ++c)
+                if (dl[c] < dl[best]) best = c;
+            std::clog << "chains " << opt.n_chains << ", printing chain " << best << "\n";
+        }
+        blockmodel.summary(best);
+        if (with_k) std::cout << blockmodel.get_KA() << " " << blockmodel.get_KB() << " ";  // :401-403
+        output_vec<uint_vec_t>(*blockmodel.get_memberships(best), std::cout);
+    };
+    // one stage per pair of the plan: merge, then a greedy sweep except after the last stage (:380-396, :425-444)
+    auto staged_merges = [&](blockmodel_t& blockmodel, metropolis_hasting& algorithm, const std::vector<int>& ka_s,
+                             const std::vector<int>& kb_s) -> bool {
+        for (size_t i = 0; i + 1 < ka_s.size(); ++i) {
+            blockmodel.agg_merge(-(ka_s[i + 1] - ka_s[i]), -(kb_s[i + 1] - kb_s[i]), 10);
+            if (i != ka_s.size() - 2) {
+                if (cooling_schedule != "abrupt_cool") {
+                    std::cerr << "Only abrupt cooling annealing is supported.";
+                    return false;
+                }
+                algorithm.anneal(blockmodel, &abrupt_cool_schedule, agg_merge_kwargs, (NA + NB) * 1, steps_await);
+            }
+        }
+        return true;
+    };
+    if (merge) {
+        try {
+            std::iota(memberships_init.begin(), memberships_init.end(), 0);  // every node its own block (:350)
+            blockmodel_t blockmodel(memberships_init, types_init, NA + NB, NA, NB, epsilon, &adj_list, opt);
+            blockmodel.init_bisbm();
+            metropolis_hasting algorithm;
+            if (nature) {  // :354-376
+                size_t tKA = NA, tKB = NB, tGroups = NA + NB;
+                const size_t ceiling = (size_t)std::ceil(std::sqrt(2. * blockmodel.get_num_edges()) / 2);
+                while (tKA >= ceiling && tKB >= ceiling) {
+                    blockmodel.agg_merge((int)std::ceil(tGroups * (sigma - 1) / sigma), 10);
+                    tKA = blockmodel.get_KA();
+                    tKB = blockmodel.get_KB();
+                    tGroups = tKA + tKB;
+                    if (cooling_schedule != "abrupt_cool") {
+                        std::cerr << "Only abrupt cooling annealing is supported.";
+                        return 1;
+                    }
+                    algorithm.anneal(blockmodel, &abrupt_cool_schedule, agg_merge_kwargs, (NA + NB) * 1, steps_await);
+                }
+            } else {  // :377-397
+                const auto plan = geospace((long)NA, (long)KA, (long)NB, (long)KB, sigma);
+                if (!staged_merges(blockmodel, algorithm, plan.first, plan.second)) return 1;
+            }
+            algorithm.anneal(blockmodel, &abrupt_cool_schedule, kwargs, sampling_steps, steps_await);  // :398
+            print_best(blockmodel, nature);
+        } catch (const std::exception& e) {
+            std::cerr << e.what() << "\n";
+            return 3;
+        }
+        return 0;
+    }
+    if (ka != KA || kb != KB) {  // the initial partition has other block counts than asked for (:419-450)
+        try {
+            int diff_a = (int)ka - (int)KA, diff_b = (int)kb - (int)KB;
+            blockmodel_t blockmodel(memberships_init, types_init, ka + kb, ka, kb, epsilon, &adj_list, opt);
+            blockmodel.init_bisbm();
+            metropolis_hasting algorithm;
+            if (diff_a >= 0 && diff_b >= 0) {
+                const auto plan = geospace((long)(KA + diff_a), (long)KA, (long)(KB + diff_b), (long)KB, sigma);
+                if (plan.first.size() == 1) blockmodel.agg_merge(diff_a, diff_b, 10);
+                if (!staged_merges(blockmodel, algorithm, plan.first, plan.second)) return 1;
+            } else {
+                blockmodel.agg_merge(diff_a, diff_b, 100);  // splits: not provided, reported by the library
+            }
+            algorithm.anneal(blockmodel, &abrupt_cool_schedule, kwargs, sampling_steps, steps_await);  // :447
+            print_best(blockmodel, false);
+        } catch (const std::exception& e) {
+            std::cerr << e.what() << "\n";
+            return 3;
+        }
+        return 0;
+    }
 
     try {
         blockmodel_t blockmodel(memberships_init, types_init, KA + KB, KA, KB, epsilon, &adj_list, opt);  // :453

@@ -123,6 +123,19 @@ int bisbm_marginals_accumulate(bisbm_handle h, uint32_t *device_counts);
 int bisbm_marginals_reset(bisbm_handle h);
 int bisbm_marginals_get(bisbm_handle h, uint32_t *counts_out /* n*kmax, host */);
 
+/* blockmodel_t::agg_merge(engine, diff_a, diff_b, nm) (blockmodel.hh, blockmodel.cc:109-206; call sites
+ * mcmc_main.cc:385,429,434,446): merge diff_a type-a and diff_b type-b blocks in every chain -- nm proposals per
+ * block (single_block_change :639-669), lowest merge dS first (compute_dS :335-372), blocks renumbered in the
+ * order of their first node (apply_block_moves :567-611), block state rebuilt.  Afterwards bisbm_get_ka_kb returns
+ * the new counts; all chains must arrive at the same (Ka,Kb), else BISBM_ERR_STATE.  Negative diffs ask for
+ * agg_split (:505-565), which reads out of range in the reference: BISBM_ERR_UNSUPPORTED.  The selection is
+ * K-scale host work, as in the reference; relabelling and the rebuild run on the device. */
+int bisbm_agg_merge(bisbm_handle h, int diff_a, int diff_b, int nm);
+
+/* blockmodel_t::agg_merge(engine, diff, nm) (blockmodel.cc:208-271; call site mcmc_main.cc:365): diff merges over
+ * both types together, proposals redrawn while the last one taken had dS = +inf. */
+int bisbm_agg_merge_total(bisbm_handle h, int diff, int nm);
+
 /* Shape queries (get_KA/get_KB blockmodel.cc:103-105, get_num_edges :81). */
 int bisbm_get_ka_kb(bisbm_handle h, uint32_t *ka, uint32_t *kb);
 int bisbm_get_sizes(bisbm_handle h, uint64_t *n, uint64_t *num_edges, uint32_t *max_degree,

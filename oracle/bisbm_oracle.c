@@ -355,7 +355,7 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     out[3] = c3;
 }
 
-enum { PHX_STEP_A = 0, PHX_STEP_B = 1, PHX_SWEEP_KEY = 2, PHX_INIT_SHUFFLE = 3 };
+enum { PHX_STEP_A = 0, PHX_STEP_B = 1, PHX_SWEEP_KEY = 2, PHX_INIT_SHUFFLE = 3, PHX_MERGE_A = 4, PHX_MERGE_B = 5 };
 
 static void phx_draw(uint64_t seed, uint32_t chain, uint32_t purpose, uint64_t idx, uint32_t out[4]) {
     uint32_t ctr[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), chain, purpose};
@@ -603,6 +603,7 @@ struct orc_model {
     uint32_t phx_chain;
     uint64_t sweeps_total;  /* Philox counters: sweeps executed over the model's lifetime */
     uint32_t shuffle_epoch; /* Philox counters: number of shuffle_bisbm calls so far */
+    uint32_t merge_epoch;   /* Philox counters: proposal rounds of agg_merge so far */
     uint64_t last_accepted, last_sweeps;
 };
 
@@ -1089,4 +1090,337 @@ double orc_anneal(orc_model *m, int schedule, float kw0, float kw1, uint64_t dur
     }
     m->last_accepted = accepted_steps;
     return (double)accepted_steps / (double)duration;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Agglomerative merges between anneals, blockmodel.cc:109-288,335-372,567-611,639-669.
+ * Negative diffs (agg_split, blockmodel.cc:505-565) are not restated: the reference reads out of
+ * range there, so there is nothing to be faithful to; the functions return -2.
+ * ---------------------------------------------------------------------------------------- */
+size_t orc_ka(const orc_model *m) { return m->ka; }
+size_t orc_kb(const orc_model *m) { return m->kb; }
+
+typedef struct {
+    size_t source, target;
+} orc_block_move;
+
+/* single_block_change, blockmodel.cc:639-669.  badj: blocks t with m[src][t] > 0, ascending (:274-288).
+ * Philox mode: the same proposal from the counter-based uniforms (u0, u1, u2) of proposal `ctr` of the
+ * current merge epoch, random-target test and target draw written as in the vertex proposal. */
+static orc_block_move single_block_change(orc_model *m, size_t src, uint64_t ctr) {
+    size_t K = m->K, KA = m->ka, KB = m->kb;
+    orc_block_move mv;
+    if ((KA == 1 && src < KA) || (KB == 1 && src >= KA)) {
+        mv.source = mv.target = src;
+        return mv;
+    }
+    size_t nadj = 0;
+    for (size_t t = 0; t < K; ++t) nadj += m->m[src * K + t] > 0;
+    size_t target;
+    if (m->rng_mode == ORC_RNG_COMPAT) {
+        if (nadj == 0) {
+            target = (size_t)(orc_mt_canonical(&m->engine) * (double)K);
+        } else {
+            size_t which = (size_t)(orc_mt_canonical(&m->engine) * (double)nadj);
+            size_t t = 0, seen = 0;
+            for (; t < K; ++t)
+                if (m->m[src * K + t] > 0 && seen++ == which) break;
+            double R_t = m->epsilon * (double)K / (m->m_r[t] + m->epsilon * (double)K);
+            if (orc_mt_canonical(&m->engine) < R_t)
+                target = (size_t)(orc_mt_canonical(&m->engine) * (double)K);
+            else
+                target = orc_mt_discrete(&m->gen, m->m + t * K, K);
+        }
+    } else {
+        uint32_t A[4], B[4];
+        uint64_t idx = ((uint64_t)m->merge_epoch << 32) | ctr;
+        phx_draw(m->phx_seed, m->phx_chain, PHX_MERGE_A, idx, A);
+        phx_draw(m->phx_seed, m->phx_chain, PHX_MERGE_B, idx, B);
+        double u0 = u53(A[0], A[1]), u1 = u53(A[2], A[3]), u2 = u53(B[0], B[1]);
+        if (nadj == 0) {
+            target = (size_t)(u0 * (double)K);
+            if (target >= K) target = K - 1;
+        } else {
+            size_t which = (size_t)(u0 * (double)nadj);
+            if (which >= nadj) which = nadj - 1;
+            size_t t = 0, seen = 0;
+            for (; t < K; ++t)
+                if (m->m[src * K + t] > 0 && seen++ == which) break;
+            if (u1 * (m->m_r[t] + m->epsilon * (double)K) < m->epsilon * (double)K) {
+                target = (size_t)(u2 * (double)K);
+                if (target >= K) target = K - 1;
+            } else { /* integer inverse CDF over row m[t][.] */
+                int64_t tot = m->m_r[t];
+                int64_t x = (int64_t)(u2 * (double)tot);
+                if (x >= tot) x = tot - 1;
+                int64_t cum = 0;
+                target = K - 1;
+                for (size_t c = 0; c < K; ++c) {
+                    cum += m->m[t * K + c];
+                    if (cum > x) {
+                        target = c;
+                        break;
+                    }
+                }
+            }
+        }
+    }
+    if (src > target) {
+        mv.source = src;
+        mv.target = target;
+    } else {
+        mv.source = target;
+        mv.target = src;
+    }
+    return mv;
+}
+
+/* compute_dS(const block_move_t&), blockmodel.cc:335-372 */
+double orc_merge_dS(const orc_model *m, size_t r, size_t s) {
+    size_t K = m->K, KA = m->ka;
+    if (r == s || (r < KA && s >= KA) || (r >= KA && s < KA)) return INFINITY;
+    double entropy0 = 0., entropy1 = 0.;
+    for (size_t idx = 0; idx < K; ++idx) {
+        int crit = (r < KA) ? (idx >= KA) : (idx < KA);
+        if (crit && m->m_r[idx] != 0) {
+            entropy0 -= orc_lgamma_fast((size_t)(m->m[r * K + idx] + 1));
+            entropy0 -= orc_lgamma_fast((size_t)(m->m[s * K + idx] + 1));
+            entropy1 -= orc_lgamma_fast((size_t)(m->m[s * K + idx] + m->m[r * K + idx] + 1));
+        }
+    }
+    entropy0 -= -orc_lgamma_fast((size_t)(m->m_r[r] + 1));
+    entropy0 -= -orc_lgamma_fast((size_t)(m->m_r[s] + 1));
+    entropy1 -= -orc_lgamma_fast((size_t)(m->m_r[r] + m->m_r[s] + 1));
+    return entropy1 - entropy0;
+}
+
+typedef struct {
+    double dS;
+    size_t ii;
+} orc_heap_item;
+static int heap_cmp(const void *a, const void *b) { /* std::pair<double,size_t> ascending = pop order of the min-heap */
+    const orc_heap_item *x = (const orc_heap_item *)a, *y = (const orc_heap_item *)b;
+    if (x->dS < y->dS) return -1;
+    if (x->dS > y->dS) return 1;
+    return x->ii < y->ii ? -1 : (x->ii > y->ii ? 1 : 0);
+}
+
+/* the groups of accepted merges: vector<set<size_t>> in creation order (blockmodel.cc:169-200) */
+typedef struct {
+    size_t *group_of_slot; /* members, grouped: members[g*K .. ] */
+    size_t *count;
+    size_t n_groups, K;
+} orc_groups;
+static int group_has(const orc_groups *G, size_t g, size_t x) {
+    for (size_t i = 0; i < G->count[g]; ++i)
+        if (G->group_of_slot[g * G->K + i] == x) return 1;
+    return 0;
+}
+static void group_add(orc_groups *G, size_t g, size_t x) {
+    if (!group_has(G, g, x)) G->group_of_slot[g * G->K + G->count[g]++] = x;
+}
+static size_t group_min(const orc_groups *G, size_t g) {
+    size_t mn = G->group_of_slot[g * G->K];
+    for (size_t i = 1; i < G->count[g]; ++i)
+        if (G->group_of_slot[g * G->K + i] < mn) mn = G->group_of_slot[g * G->K + i];
+    return mn;
+}
+/* one accepted move (source, target): :172-184 */
+static void accept_move(orc_groups *G, unsigned char *in_e, size_t src, size_t tgt) {
+    if (!in_e[src] && !in_e[tgt]) {
+        size_t g = G->n_groups++;
+        G->count[g] = 0;
+        group_add(G, g, src);
+        group_add(G, g, tgt);
+    } else {
+        for (size_t g = 0; g < G->n_groups; ++g)
+            if (group_has(G, g, tgt) || group_has(G, g, src)) {
+                group_add(G, g, src);
+                group_add(G, g, tgt);
+                break;
+            }
+    }
+    in_e[src] = in_e[tgt] = 1;
+}
+
+/* apply_block_moves, blockmodel.cc:567-611.  Returns 0, or -1 on the reference's sanity failure (exit(0) there). */
+static int apply_block_moves(orc_model *m, const unsigned char *in_e, const orc_groups *G) {
+    size_t n = m->n;
+    for (size_t v = 0; v < n; ++v) {
+        uint32_t mb = m->labels[v];
+        if (in_e[mb]) {
+            for (size_t g = 0; g < G->n_groups; ++g)
+                if (group_has(G, g, mb)) mb = (uint32_t)group_min(G, g); /* (keeps scanning with the new label) */
+        }
+        m->labels[v] = mb;
+    }
+    int *n2o = (int *)malloc(sizeof(int) * (m->K + 1));
+    for (size_t i = 0; i <= m->K; ++i) n2o[i] = -1;
+    size_t KA = 0, KB = 0, cnt = 0;
+    for (size_t v = 0; v < n; ++v) {
+        uint32_t mb = m->labels[v];
+        if (n2o[mb] == -1) n2o[mb] = (int)cnt++;
+        mb = (uint32_t)n2o[mb];
+        m->labels[v] = mb;
+        if (v < m->na) {
+            if (mb > KA) KA = mb;
+        } else {
+            if (mb > KB) KB = mb;
+        }
+    }
+    free(n2o);
+    KB -= KA;
+    KA += 1;
+    m->ka = KA;
+    m->kb = KB;
+    m->K = KA + KB;
+    if (cnt != m->K) return -1;
+    orc_init_bisbm(m);
+    return 0;
+}
+
+/* the proposal round shared by both agg_merge overloads (:147-159 / :231-243): nm proposals per listed
+ * block, de-duplicated on "source>target", keyed by dS */
+static size_t propose_round(orc_model *m, size_t first, size_t count, int nm, orc_block_move *moves,
+                            orc_heap_item *heap) {
+    size_t K = m->K, ii = 0;
+    unsigned char *seen = (unsigned char *)calloc(K * K, 1);
+    uint64_t ctr = 0;
+    for (size_t b = first; b < first + count; ++b)
+        for (int i = 0; i < nm; ++i) {
+            orc_block_move mv = single_block_change(m, b, ctr++);
+            if (!seen[mv.source * K + mv.target]) {
+                seen[mv.source * K + mv.target] = 1;
+                moves[ii] = mv;
+                heap[ii].dS = orc_merge_dS(m, mv.source, mv.target);
+                heap[ii].ii = ii;
+                ++ii;
+            }
+        }
+    free(seen);
+    m->merge_epoch++;
+    qsort(heap, ii, sizeof(orc_heap_item), heap_cmp);
+    return ii;
+}
+
+/* agg_merge(engine, diff_a, diff_b, nm), blockmodel.cc:109-206.  0 ok, -1 sanity failure, -2 negative diff,
+ * -3 no progress possible (the reference would recurse without end). */
+int orc_agg_merge(orc_model *m, int diff_a, int diff_b, int nm) {
+    for (int depth = 0; depth < 10000; ++depth) {
+        if (diff_a < 0 || diff_b < 0) return -2;
+        if (diff_a + diff_b == 0) return 0;
+        size_t K = m->K, first, count;
+        if (diff_a > 0 && diff_b == 0) {
+            first = 0;
+            count = m->ka;
+        } else if (diff_a == 0 && diff_b > 0) {
+            first = m->ka;
+            count = m->kb;
+        } else {
+            first = 0;
+            count = K;
+        }
+        orc_block_move *moves = (orc_block_move *)malloc(sizeof(orc_block_move) * (size_t)nm * count + 1);
+        orc_heap_item *heap = (orc_heap_item *)malloc(sizeof(orc_heap_item) * (size_t)nm * count + 1);
+        size_t nq = propose_round(m, first, count, nm, moves, heap);
+        unsigned char *in_e = (unsigned char *)calloc(K, 1);
+        orc_groups G = {(size_t *)malloc(sizeof(size_t) * K * K), (size_t *)calloc(K, sizeof(size_t)), 0, K};
+        int recurse = 0;
+        size_t merged = 0;
+        for (size_t qi = 0; qi < nq && diff_a + diff_b != 0; ++qi) {
+            if (heap[qi].dS == INFINITY) { /* :163-168 */
+                recurse = 1;
+                break;
+            }
+            orc_block_move mv = moves[heap[qi].ii];
+            if (mv.source < m->ka && diff_a != 0) {
+                if (!(in_e[mv.source] && in_e[mv.target])) {
+                    diff_a -= 1;
+                    accept_move(&G, in_e, mv.source, mv.target);
+                    ++merged;
+                }
+            } else if (mv.source >= m->ka && diff_b != 0) {
+                if (!(in_e[mv.source] && in_e[mv.target])) {
+                    diff_b -= 1;
+                    accept_move(&G, in_e, mv.source, mv.target);
+                    ++merged;
+                }
+            }
+        }
+        int rc = apply_block_moves(m, in_e, &G);
+        free(moves);
+        free(heap);
+        free(in_e);
+        free(G.group_of_slot);
+        free(G.count);
+        if (rc) return rc;
+        if (!recurse) return 0;
+        /* the reference recurses without end when the remaining budget asks for merges in a type that is down
+         * to one block */
+        if (merged == 0 && !((diff_a > 0 && m->ka > 1) || (diff_b > 0 && m->kb > 1))) return -3;
+    }
+    return -3;
+}
+
+/* agg_merge(engine, diff, nm), blockmodel.cc:208-271 (--nature) */
+int orc_agg_merge_total(orc_model *m, int diff, int nm) {
+    if (diff == 0) return 0;
+    if (diff < 0) return -2;
+    size_t K = m->K;
+    orc_block_move *moves = (orc_block_move *)malloc(sizeof(orc_block_move) * (size_t)nm * K + 1);
+    orc_heap_item *heap = (orc_heap_item *)malloc(sizeof(orc_heap_item) * (size_t)nm * K + 1);
+    unsigned char *in_e = (unsigned char *)calloc(K, 1);
+    orc_groups G = {(size_t *)malloc(sizeof(size_t) * K * K), (size_t *)calloc(K, sizeof(size_t)), 0, K};
+    const int DIFF = diff;
+    int minS = 1, rounds = 0;
+    while (minS) {
+        if (++rounds > 10000) {
+            free(moves), free(heap), free(in_e), free(G.group_of_slot), free(G.count);
+            return -3;
+        }
+        G.n_groups = 0;
+        memset(in_e, 0, K);
+        size_t nq = propose_round(m, 0, K, nm, moves, heap);
+        for (size_t qi = 0; qi < nq && diff != 0; ++qi) {
+            orc_block_move mv = moves[heap[qi].ii];
+            if (!(in_e[mv.source] && in_e[mv.target])) {
+                diff -= 1;
+                accept_move(&G, in_e, mv.source, mv.target);
+            }
+            minS = heap[qi].dS == INFINITY;
+        }
+        diff = DIFF;
+    }
+    int rc = apply_block_moves(m, in_e, &G);
+    free(moves), free(heap), free(in_e), free(G.group_of_slot), free(G.count);
+    return rc;
+}
+
+/* geospace, support/util.hh:99-145 (ints).  Writes at most cap entries per side, returns the count. */
+size_t orc_geospace(long start_a_in, long end_a_in, long start_b_in, long end_b_in, double ratio, int *out_a,
+                    int *out_b, size_t cap) {
+    if (ratio <= 1.) {
+        out_a[0] = out_b[0] = 0;
+        return 1;
+    }
+    int reverse = 0;
+    int start_a = (int)start_a_in, end_a = (int)end_a_in, start_b = (int)start_b_in, end_b = (int)end_b_in;
+    if (start_a - end_a < start_b - end_b) {
+        start_a = (int)start_b_in, end_a = (int)end_b_in;
+        start_b = (int)start_a_in, end_b = (int)end_a_in;
+        reverse = 1;
+    }
+    int *ga = reverse ? out_b : out_a, *gb = reverse ? out_a : out_b;
+    size_t n = 0, i = 0;
+    int d = start_a;
+    while (d > end_a && n + 1 < cap) {
+        ga[n++] = d;
+        i += 1;
+        d = (int)floor(start_a / pow(ratio, (double)i));
+    }
+    ga[n++] = end_a;
+    double r_ = pow((double)(start_b / end_b), 1. / (double)(n - 1)); /* integer division, :134 */
+    for (size_t idx = 0; idx + 1 < n; ++idx) gb[idx] = (int)floor(start_b / pow(r_, (double)idx));
+    gb[n - 1] = end_b;
+    return n;
 }

@@ -113,6 +113,15 @@ uint64_t orc_last_accepted(const orc_model *m);
 uint64_t orc_last_sweeps(const orc_model *m);
 uint64_t orc_total_sweeps(const orc_model *m);
 
+/* agglomerative merges between anneals (blockmodel.cc:109-288,335-372,567-611,639-669); see the .c file */
+size_t orc_ka(const orc_model *m);
+size_t orc_kb(const orc_model *m);
+double orc_merge_dS(const orc_model *m, size_t r, size_t s);
+int orc_agg_merge(orc_model *m, int diff_a, int diff_b, int nm);
+int orc_agg_merge_total(orc_model *m, int diff, int nm);
+size_t orc_geospace(long start_a, long end_a, long start_b, long end_b, double ratio, int *out_a, int *out_b,
+                    size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,6 +101,19 @@ def lib():
     L.orc_get_n_r.argtypes = [C.c_void_p, _i32p]
     L.orc_get_eta.argtypes = [C.c_void_p, _u32p]
     L.orc_get_vlist.argtypes = [C.c_void_p, _u32p]
+    L.orc_ka.restype = C.c_size_t
+    L.orc_ka.argtypes = [C.c_void_p]
+    L.orc_kb.restype = C.c_size_t
+    L.orc_kb.argtypes = [C.c_void_p]
+    L.orc_merge_dS.restype = C.c_double
+    L.orc_merge_dS.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+    L.orc_agg_merge.restype = C.c_int
+    L.orc_agg_merge.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.orc_agg_merge_total.restype = C.c_int
+    L.orc_agg_merge_total.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.orc_geospace.restype = C.c_size_t
+    L.orc_geospace.argtypes = [C.c_long, C.c_long, C.c_long, C.c_long, C.c_double, C.POINTER(C.c_int),
+                               C.POINTER(C.c_int), C.c_size_t]
     L.free = C.CDLL(None).free
     L.free.argtypes = [C.c_void_p]
     _lib = L
@@ -212,6 +225,26 @@ class OracleModel:
         kw = list(kwargs) + [0.0, 0.0]
         return self.L.orc_anneal(self.h, SCHEDULES[schedule], kw[0], kw[1], duration, steps_await)
 
+    def _refresh_k(self):
+        self.ka, self.kb = self.L.orc_ka(self.h), self.L.orc_kb(self.h)
+        self.K = self.ka + self.kb
+
+    def merge_dS(self, r, s):
+        """compute_dS(block_move_t), blockmodel.cc:335-372"""
+        return self.L.orc_merge_dS(self.h, r, s)
+
+    def agg_merge(self, diff_a, diff_b, nm):
+        """blockmodel_t::agg_merge(engine, diff_a, diff_b, nm), blockmodel.cc:109-206"""
+        rc = self.L.orc_agg_merge(self.h, diff_a, diff_b, nm)
+        self._refresh_k()
+        return rc
+
+    def agg_merge_total(self, diff, nm):
+        """blockmodel_t::agg_merge(engine, diff, nm), blockmodel.cc:208-271"""
+        rc = self.L.orc_agg_merge_total(self.h, diff, nm)
+        self._refresh_k()
+        return rc
+
     def entropy(self):
         return self.L.orc_entropy(self.h)
 
@@ -276,3 +309,11 @@ def load_graph(name):
     a, b = load_edge_list(path)
     rowptr, col = edge_to_csr(a, b, na + nb)
     return rowptr, col, na, nb
+
+
+def geospace(start_a, end_a, start_b, end_b, ratio):
+    """support/util.hh:99-145"""
+    cap = 4096
+    a, b = (C.c_int * cap)(), (C.c_int * cap)()
+    n = lib().orc_geospace(start_a, end_a, start_b, end_b, float(ratio), a, b, cap)
+    return list(a[:n]), list(b[:n])

@@ -209,6 +209,95 @@ def test_marginalize_driver_matches_oracle_samples():
     assert (lab == want.argmax(axis=1) + base).all()
 
 
+# ------------------------------------------------------------------ agglomerative merges
+def _merge_schedule(o, g, stages, mh, n):
+    """mcmc_main.cc:379-396 / :425-444: one agg_merge per geospace stage, a greedy sweep (abrupt_cool, kwargs {0})
+    between stages."""
+    ka_s, kb_s = stages
+    for i in range(len(ka_s) - 1):
+        da, db = ka_s[i] - ka_s[i + 1], kb_s[i] - kb_s[i + 1]
+        assert o.agg_merge(da, db, 10) == 0
+        g.agg_merge(da, db, 10)
+        assert (g.KA, g.KB) == (o.ka, o.kb) == (ka_s[i + 1], kb_s[i + 1])
+        assert_state_equal(g, o)
+        if i != len(ka_s) - 2:
+            ro = o.anneal("abrupt_cool", [0.0], n, BIG)
+            rg = mh.anneal(g, "abrupt_cool", [0.0], n, BIG)
+            assert rg == ro
+            assert_state_equal(g, o)
+
+
+@pytest.mark.parametrize("mode", ["compat", "philox"])
+def test_agg_merge_from_singletons_matches_oracle(mode):
+    """--merge on southernWomen (mcmc_main.cc:349-399): every node its own block, merged down to 5 + 5."""
+    rowptr, col, na, nb = O.load_graph("southernWomen")
+    n = na + nb
+    labels = np.arange(n, dtype=np.uint32)
+    o = O.OracleModel(rowptr, col, na, nb, na, nb, 0.001, labels)
+    if mode == "compat":
+        o.seed_compat(42, 43)
+        g = gpu_model(rowptr, col, na, nb, na, nb, 0.001, labels, rng="compat", seed=42, gen_seed=43)
+    else:
+        o.seed_philox(9, 2)
+        g = gpu_model(rowptr, col, na, nb, na, nb, 0.001, labels, rng="philox", seed=9, first_chain_id=2)
+    o.init_bisbm()
+    g.init_bisbm()
+    mh = B.MetropolisHasting()
+    _merge_schedule(o, g, O.geospace(na, 5, nb, 5, 1.01), mh, n)
+    ro = o.anneal("abrupt_cool", [50.0], 20 * n, BIG)
+    rg = mh.anneal(g, "abrupt_cool", [50.0], 20 * n, BIG)
+    assert rg == ro
+    assert_state_equal(g, o)
+    assert g.entropy()[0] == pytest.approx(o.entropy(), rel=1e-12)
+
+
+@pytest.mark.parametrize("mode", ["compat", "philox"])
+def test_agg_merge_down_from_initial_partition(mode):
+    """mcmc_main.cc:402-450: an initial partition with more blocks than asked for (12 + 15 on n_1000) merged down
+    to 4 + 6 in geometric stages; also the one-shot merge over both types (blockmodel.cc:208-271)."""
+    rowptr, col, na, nb = O.load_graph("n_1000")
+    n = na + nb
+    labels = O.contiguous_labels(na, nb, 12, 15)
+    o = O.OracleModel(rowptr, col, na, nb, 12, 15, 1.0, labels)
+    if mode == "compat":
+        o.seed_compat(5, 6)
+        g = gpu_model(rowptr, col, na, nb, 12, 15, 1.0, labels, rng="compat", seed=5, gen_seed=6)
+    else:
+        o.seed_philox(31, 0)
+        g = gpu_model(rowptr, col, na, nb, 12, 15, 1.0, labels, rng="philox", seed=31)
+    o.shuffle_bisbm()
+    g.shuffle_bisbm()
+    mh = B.MetropolisHasting()
+    _merge_schedule(o, g, O.geospace(12, 6, 15, 8, 1.2), mh, n)
+    assert o.agg_merge_total(4, 10) == 0   # --nature style: 4 merges wherever they are cheapest
+    g.agg_merge(4, None, 10)
+    assert (g.KA, g.KB) == (o.ka, o.kb) and g.K == 10
+    assert_state_equal(g, o)
+    ro = o.anneal("constant", [1.0], 3 * n, BIG)
+    rg = mh.anneal(g, "constant", [1.0], 3 * n, BIG)
+    assert rg == ro
+    assert_state_equal(g, o)
+    with pytest.raises(B.BisbmError):      # agg_split is not provided (reference reads out of range there)
+        g.agg_merge(-1, 0, 10)
+
+
+def test_agg_merge_many_chains_philox():
+    """64 chains merged at once; every chain equals its own oracle run."""
+    rowptr, col, na, nb = O.load_graph("n_1000")
+    labels = O.contiguous_labels(na, nb, 8, 9)
+    chains = 64
+    g = gpu_model(rowptr, col, na, nb, 8, 9, 1.0, labels, n_chains=chains, rng="philox", seed=77, first_chain_id=10)
+    g.shuffle_bisbm()
+    g.agg_merge(4, 3, 10)
+    assert (g.KA, g.KB) == (4, 6)
+    for c in range(0, chains, 7):
+        o = O.OracleModel(rowptr, col, na, nb, 8, 9, 1.0, labels)
+        o.seed_philox(77, 10 + c)
+        o.shuffle_bisbm()
+        assert o.agg_merge(4, 3, 10) == 0
+        assert_state_equal(g, o, c)
+
+
 def test_anneal_splits_compose_on_device():
     rowptr, col, na, nb = O.load_graph("n_1000")
     labels = O.contiguous_labels(na, nb, 4, 6)
@@ -302,6 +391,31 @@ def test_cli_golden(golden):
     assert r.returncode == 0, r.stderr
     assert r.stdout == " ".join(map(str, g["labels"])) + " \n"
     assert "acceptance ratio 0.248264" in r.stderr and "(Ka, Kb) = (5, 5) " in r.stderr and "entropy: 221.095" in r.stderr
+
+
+def test_cli_merge_matches_oracle_replay():
+    """`mcmc --merge` (mcmc_main.cc:349-399) on southernWomen against the same driver replayed with the oracle:
+    one block per node, staged merges down to 5 + 5 with greedy sweeps in between, final abrupt_cool anneal."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "bipartitesbm-mcmc_amd", "bin", "mcmc")
+    r = subprocess.run([cli, "-e", os.path.join(O.GOLDEN, "southernWomen.edgelist"), "-y", "18", "14", "-n", "18", "14", "-z", "5", "5",
+                        "--merge", "-t", "3200", "-x", "100000", "-c", "abrupt_cool", "-a", "320", "-E", "0.001",
+                        "-d", "42", "--gen_seed", "43"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rowptr, col, na, nb = O.load_graph("southernWomen")
+    n = na + nb
+    o = O.OracleModel(rowptr, col, na, nb, na, nb, 0.001, np.arange(n, dtype=np.uint32))
+    o.seed_compat(42, 43)
+    o.init_bisbm()
+    ka_s, kb_s = O.geospace(na, 5, nb, 5, 1.01)
+    for i in range(len(ka_s) - 1):
+        assert o.agg_merge(ka_s[i] - ka_s[i + 1], kb_s[i] - kb_s[i + 1], 10) == 0
+        if i != len(ka_s) - 2:
+            o.anneal("abrupt_cool", [0.0], n, 100000)
+    o.anneal("abrupt_cool", [320.0], 3200, 100000)
+    assert r.stdout == " ".join(map(str, o.memberships())) + " \n"
+    assert "(Ka, Kb) = (5, 5) " in r.stderr
 
 
 # ------------------------------------------------------------------ full size: properties

@@ -360,3 +360,81 @@ def test_edge_list_quirks_without_reference(tmp_path):
     assert list(a) == [0, 1, 1, 2, 0, 3, 4] and list(b) == [5, 6, 6, 7, 7, 7, 8]
     rowptr, col = O.edge_to_csr(np.array([0, 1, 0]), np.array([2, 2, 2]), 3)
     assert list(rowptr) == [0, 2, 3, 6] and list(col) == [2, 2, 2, 0, 1, 0]
+
+
+# ------------------------------------------------------------------ agglomerative merges
+def _edge_entropy(m_full, m_r):
+    """The terms compute_dS(block_move_t) (blockmodel.cc:335-372) keeps: -sum lg(m_ab + 1) over the a x b quadrant
+    plus sum lg(m_r + 1)."""
+    libm = C.CDLL("libm.so.6")
+    libm.lgamma.restype = C.c_double
+    libm.lgamma.argtypes = [C.c_double]
+    K = len(m_r)
+    s = 0.0
+    for i in range(K):
+        for j in range(i + 1, K):
+            s -= libm.lgamma(float(m_full[i, j] + 1))
+        s += libm.lgamma(float(m_r[i] + 1))
+    return s
+
+
+def test_merge_dS_is_the_change_of_the_edge_terms():
+    rowptr, col, na, nb = O.load_graph("n_1000")
+    labels = O.contiguous_labels(na, nb, 5, 7)
+    o = O.OracleModel(rowptr, col, na, nb, 5, 7, 1.0, labels)
+    o.init_bisbm()
+    before = _edge_entropy(o.m(), o.m_r())
+    for r, s in [(3, 1), (11, 6), (4, 0)]:
+        merged = labels.copy()
+        merged[merged == r] = s
+        merged[merged > r] -= 1  # keep the numbering compact
+        ka2, kb2 = (4, 7) if r < 5 else (5, 6)
+        o2 = O.OracleModel(rowptr, col, na, nb, ka2, kb2, 1.0, merged)
+        o2.init_bisbm()
+        want = _edge_entropy(o2.m(), o2.m_r()) - before
+        assert o.merge_dS(r, s) == pytest.approx(want, rel=1e-10)
+    assert o.merge_dS(2, 2) == math.inf and o.merge_dS(7, 2) == math.inf  # same block, cross type
+
+
+@pytest.mark.parametrize("mode", ["compat", "philox"])
+def test_agg_merge_properties(mode):
+    """Block counts reached, labels compact with type-a blocks first and numbered by first appearance, the block
+    state equal to a recount, deterministic for a fixed seed; the --nature overload and the refusals."""
+    rowptr, col, na, nb = O.load_graph("n_1000")
+    labels = O.contiguous_labels(na, nb, 9, 11)
+
+    def fresh():
+        o = O.OracleModel(rowptr, col, na, nb, 9, 11, 1.0, labels)
+        o.seed_compat(3, 4) if mode == "compat" else o.seed_philox(3, 4)
+        o.shuffle_bisbm()
+        return o
+    o = fresh()
+    assert o.agg_merge(4, 5, 10) == 0
+    assert (o.ka, o.kb) == (5, 6)
+    lab = o.memberships()
+    assert set(lab[:na]) == set(range(5)) and set(lab[na:]) == set(range(5, 11))
+    firsts = [int(np.argmax(lab == k)) for k in range(11)]
+    assert firsts == sorted(firsts)  # renumbered in the order of first appearance (blockmodel.cc:585-590)
+    o2 = O.OracleModel(rowptr, col, na, nb, 5, 6, 1.0, lab)
+    o2.init_bisbm()
+    assert (o.m() == o2.m()).all() and (o.m_r() == o2.m_r()).all() and (o.n_r() == o2.n_r()).all()
+    p = fresh()
+    p.agg_merge(4, 5, 10)
+    assert (p.memberships() == lab).all()
+    assert o.agg_merge_total(3, 10) == 0 and o.K == 8
+    assert o.agg_merge(0, 0, 10) == 0 and o.K == 8
+    assert o.agg_merge(-1, 0, 10) == -2          # agg_split is not restated (reference reads out of range there)
+    one = O.OracleModel(rowptr, col, na, nb, 1, 3, 1.0, O.contiguous_labels(na, nb, 1, 3))
+    one.seed_compat(1, 2) if mode == "compat" else one.seed_philox(1, 2)
+    one.init_bisbm()
+    assert one.agg_merge(1, 0, 10) == -3         # the reference would recurse without end
+
+
+def test_geospace_known_values():
+    """support/util.hh:99-145, worked by hand: the larger drop steps by floor(start / ratio^i)."""
+    assert O.geospace(18, 5, 14, 5, 1.5) == ([18, 12, 8, 5], [14, 11, 8, 5])
+    assert O.geospace(10, 10, 10, 10, 1.01) == ([10], [10])
+    a, b = O.geospace(500, 4, 500, 6, 1.01)
+    assert a[0] == 500 and a[-1] == 4 and b[0] == 500 and b[-1] == 6 and len(a) == len(b)
+    assert all(x >= y for x, y in zip(a, a[1:])) and all(x >= y for x, y in zip(b, b[1:]))
+    assert O.geospace(5, 2, 9, 3, 1.0) == ([0], [0])  # ratio <= 1
