@@ -15,7 +15,14 @@ HEADERS = ["bisbm_device.hpp", "bisbm_kernels.hpp", os.path.join("..", "host", "
            os.path.join("..", "host", "mcmc_main.cpp"), os.path.join("..", "..", "include", "bisbm.h"),
            os.path.join("..", "..", "include", "bisbm_io.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function",
+         # The step loop is a tree of wave-uniform branches (scalar compares, ballots).  Left to its default the
+         # backend structurizes the whole loop -- flag registers, chains of always-taken jumps and a copy of every
+         # loop-carried register on every path (~40 issue slots per step); told to leave uniform regions alone it
+         # emits the branches as written and updates the block state in place.
+         "-mllvm", "-structurizecfg-skip-uniform-regions=true",
+         # single-lane LDS atomics (sum of accepted dS, accepted count) stay single instructions
+         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 
 def hipcc():

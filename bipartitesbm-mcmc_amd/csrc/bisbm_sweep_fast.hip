@@ -107,6 +107,13 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     uint32_t* const hand_base = lds32 + o_hand;             // per-chunk lane data handed from the feeder wave
     int32_t* const slow_hist = (int32_t*)(lds32 + o_slow);  // 64 counters for rows longer than 64
     uint32_t* const stop_flag = lds32 + o_flag;
+    // anneal()'s running numbers live in LDS, not in registers: most steps do not touch them at all, and as
+    // loop-carried registers they cost a set of copies on every path of the step loop
+    const uint32_t o_books = (o_flag + 4u + 1u) & ~1u;
+    double* const bk_cum = (double*)(lds32 + o_books);            // blockmodel_t::entropy_, running sum of accepted dS
+    double* const bk_emin = (double*)(lds32 + o_books + 2);       // entropy_min_ (metropolis_hasting.cc:75)
+    unsigned long long* const bk_u = (unsigned long long*)(lds32 + o_books + 4);    // steps below T = 1 since the last minimum
+    unsigned long long* const bk_acc = (unsigned long long*)(lds32 + o_books + 6);  // accepted steps of this call
     const bool is_main = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;  // wave 0 steps, wave 1 feeds
 
     uint8_t* const labels = p.labels + (size_t)chain * p.label_stride;
@@ -122,7 +129,13 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
         for (uint32_t i = lane; i < ka * kb; i += kWave) mq[(i / kb) * S + (i % kb)] = m_g[i];
         if (EL)
             for (uint32_t i = lane; i < K * D; i += kWave) eta_l[i] = eta_g[i];
-        if (lane == 0) *stop_flag = 0;
+        if (lane == 0) {
+            *stop_flag = 0;
+            *bk_cum = sc->cum_dS;
+            *bk_emin = INFINITY;  // metropolis_hasting.cc:75
+            *bk_u = 0;
+            *bk_acc = 0;
+        }
     }
     // The stepping wave shares its SIMD with the feeder wave of another chain (four chains per CU): it is the
     // critical path, so it issues first whenever both have an instruction ready.
@@ -130,7 +143,6 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     int mrA = lane < ka ? mr_g[lane] : 0, nrA = lane < ka ? nr_g[lane] : 0;
     int mrB = lane < kb ? mr_g[ka + lane] : 0, nrB = lane < kb ? nr_g[ka + lane] : 0;
     __syncthreads();
-    double cum_dS = sc->cum_dS;
     uint64_t sweeps_total = sc->sweeps_total;
 
     auto eta_rd = [&](uint32_t idx) -> uint32_t { return EL ? eta_l[idx] : eta_g[idx]; };
@@ -157,8 +169,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     LogQConsts lqc = log_q_consts();  // log_q closed form
     __asm__ volatile("" : "+v"(lqc.nc0l2e), "+v"(lqc.c1c0), "+v"(lqc.c1), "+v"(lqc.c2c0), "+v"(lqc.lfc));
     BISBM_PIN(c_576, 576.0);                       // 24^2: tier test k^2 > 576 n
-    uint64_t accepted_steps = 0, u_cnt = 0, sweeps_done = 0;
-    double entropy_min = INFINITY;  // metropolis_hasting.cc:75
+    uint64_t sweeps_done = 0;
     double rate = 0.;
     bool stopped = false;
 #ifdef BISBM_STAMPS
@@ -301,15 +312,24 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     prop_l |= 0x80000000u;
 
                 // anneal()'s bookkeeping after a step, metropolis_hasting.cc:85-94
-                auto book = [&](bool ok, double T) {
-                    if (ok) ++accepted_steps;
+                // (every lane reads and writes the same LDS words with the same values; the sum of accepted dS and the
+                // accepted count are bumped by lane 0 where a step is accepted)
+                auto book_min = [&](bool ok, double T) {
                     if (track_min) {
-                        if (ok && cum_dS < entropy_min) {
-                            entropy_min = cum_dS;
-                            u_cnt = 0;
+                        wfence();
+                        const double c = *bk_cum;
+                        if (ok && c < *bk_emin) {
+                            *bk_emin = c;
+                            *bk_u = 0;
                         }
-                        if (T < 1.) ++u_cnt;
+                        wfence();
+                        if (T < 1.) *bk_u = *bk_u + 1;
+                        wfence();
                     }
+                };
+                auto book = [&](bool ok, double T) {
+                    if (ok && lane == 0) atomicAdd(bk_acc, 1ull);
+                    book_min(ok, T);
                 };
 
                 // ---- any step (all the rare cases included): the definition the hot path below specialises ----
@@ -439,7 +459,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                             mq[a_rt] = m_rt - k;
                             mq[a_st] = m_st + k;
                         }
-                        cum_dS += dS;  // :500
+                        if (lane == 0) atomicAdd(bk_cum, dS);  // :500
                         wfence();
                     }
                     book(ok, T);
@@ -449,17 +469,8 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                 const unsigned long long last_own_bit = 1ull << (k_own - 1);
                 const double invT_const = 1.0 / T_const;
                 // One step.  Early returns only (each is a jump to the loop latch); the rare cases leave through
-                // step_general at the top, before anything is computed.
-                auto booked = [&](uint32_t ok_i, double T) {  // ok_i = 1: counts as accepted (metropolis_hasting.cc:87)
-                    accepted_steps += ok_i;
-                    if (track_min) {
-                        if (ok_i && cum_dS < entropy_min) {
-                            entropy_min = cum_dS;
-                            u_cnt = 0;
-                        }
-                        if (T < 1.) ++u_cnt;
-                    }
-                };
+                // step_general at the top, before anything is computed.  A rejected step changes nothing, not even a
+                // register, unless the early-stop bookkeeping is on (T < 1).
                 auto step = [&](uint32_t q) {
                     const double T = CT ? T_const : temperature_of(p, sweep_step0 + node_base + vi0 + q);  // :84
                     FSTAMP(0);
@@ -490,7 +501,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     const uint32_t s_loc = (uint32_t)__builtin_ctzll(hit);
                     FSTAMP(2);
                     if (s_loc == r_loc) {  // r == s: accepted as is (T > 0 here), nothing changes (:109-112)
-                        booked(n_r_r != 1, T);
+                        book(n_r_r != 1, T);
                         return;
                     }
                     const uint32_t r = own_base + r_loc, s = own_base + s_loc;
@@ -559,13 +570,13 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     const unsigned long long b_far = __builtin_amdgcn_ballot_w64(fabs(lhs - est) > c_tol * est);
                     FSTAMP(7);
                     if ((b_lt | ~b_far) == 0) {  // clearly rejected
-                        booked(0, T);
+                        book_min(false, T);
                         return;
                     }
                     unsigned long long b_acc = b_lt;
                     if (__builtin_expect(b_far == 0, 0)) b_acc = __builtin_amdgcn_ballot_w64(lhs < accu1 * exp(z));
                     if (b_acc == 0 || n_r_r == 1) {  // (:467-471: veto after the draw)
-                        booked(0, T);
+                        book_min(false, T);
                         return;
                     }
                     // ---- apply_mcmc_moves, blockmodel.cc:461-503 ----
@@ -575,6 +586,8 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                         eta_wr(r * D + deg, (uint32_t)(eta_r - 1));
                         eta_wr(s * D + deg, (uint32_t)(eta_s + 1));
                         labels[v] = (uint8_t)s;
+                        atomicAdd(bk_cum, dS);  // :500
+                        atomicAdd(bk_acc, 1ull);
                     }
                     const int dl = (int)min(lane ^ r_loc, 1u) - (int)min(lane ^ s_loc, 1u);  // +1 on lane s_loc, -1 on r_loc
                     mr_own += __mul24(ideg, dl);
@@ -583,10 +596,9 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                         mq[a_rt] = m_rt - k;
                         mq[a_st] = m_st + k;
                     }
-                    cum_dS += dS;  // :500
                     wfence();
                     FSTAMP(8);
-                    booked(1, T);
+                    book_min(true, T);
                 };
                 for (uint32_t q = 0; q < cnt; ++q) step(q);
             };
@@ -610,15 +622,15 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
 
         ++sweeps_total;
         sweeps_done = sweep + 1;
-        if (is_main && lane == 0 && u_cnt >= p.steps_await) *stop_flag = 1;  // metropolis_hasting.cc:96-98
+        if (is_main && lane == 0 && *bk_u >= p.steps_await) *stop_flag = 1;  // metropolis_hasting.cc:96-98
         __syncthreads();
         if (__builtin_amdgcn_readfirstlane((int)*stop_flag)) {  // (scalar: the sweep loop has no divergent exit)
-            rate = (double)accepted_steps / (double)((sweep + 1) * (uint64_t)n);
+            rate = (double)*bk_acc / (double)((sweep + 1) * (uint64_t)n);
             stopped = true;
             break;
         }
     }
-    if (!stopped) rate = (double)accepted_steps / (double)p.duration;  // :100
+    if (!stopped) rate = (double)*bk_acc / (double)p.duration;  // :100
 
     // chain state -> HBM (wave 0)
     __syncthreads();
@@ -639,10 +651,10 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
         for (int i = 0; i < 12; ++i) atomicAdd(&g_fast_stamps[i], st_acc[i]);
 #endif
     if (lane == 0) {
-        sc->cum_dS = cum_dS;
+        sc->cum_dS = *bk_cum;
         sc->sweeps_total = sweeps_total;
         sc->last_rate = rate;
-        sc->last_accepted = accepted_steps;
+        sc->last_accepted = *bk_acc;
         sc->last_sweeps = sweeps_done;
     }
 }
@@ -651,7 +663,7 @@ size_t sweep_fast_lds_bytes(uint32_t ka, uint32_t kb, uint32_t maxdeg, bool eta_
     const uint32_t K = ka + kb, D = maxdeg + 1, S = kb | 1u;
     const uint32_t row_cap = maxdeg < (uint32_t)kWave ? maxdeg : (uint32_t)kWave, RS = row_cap | 1u;
     const size_t dwords = (size_t)ka * S + (eta_in_lds ? (size_t)K * D : 0) + (size_t)kWave * RS +
-                          2 * (size_t)kWave * (kHistStride / 4) + 2 * (size_t)kHandWords * kWave + kWave + 4;
+                          2 * (size_t)kWave * (kHistStride / 4) + 2 * (size_t)kHandWords * kWave + kWave + 4 + 10;
     // the step reads m[.][lane] for all 64 lanes whatever ka, kb are (idle lanes are masked after the read):
     // dword index <= 63 * S + 63 must be inside the allocation
     const size_t reach = 63 * (size_t)S + 64;
