@@ -162,7 +162,8 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     const double T_const = (double)p.kw0;  // CT: constant schedule (metropolis_hasting.cc:25-28)
     // m_r <= E: with E + maxdeg inside the log_q table no step can use the closed-form tier of the hot path
     const bool never_direct = (p.rowptr[n] >> 1) + p.maxdeg <= (uint32_t)kQNmax;
-    const bool track_min = !CT || T_const < 1.;  // the early-stop bookkeeping can only ever fire below T = 1
+    // the early-stop bookkeeping can only ever fire below T = 1 (a scalar word, not a lane mask: one s_cmp to test)
+    const uint32_t track_min = (uint32_t)__builtin_amdgcn_readfirstlane((!CT || T_const < 1.) ? 1 : 0);
     // constants of the hot step (log_q closed form, accept filter)
     BISBM_PIN(c_l2e, 0x1.71547652b82fep+0);        // log2(e)
     BISBM_PIN(c_tol, 1e-5);                        // accept filter margin
@@ -199,8 +200,9 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
             const int eoff_l = (lane & 7u) < 6 ? 1 : ((lane & 1u) ? 2 : 0);       // eta_r+1, eta_s+1, eta_r, eta_s+2
             const int dq_l = (lane & 2u) ? ((lane & 1u) ? 1 : -1) : 0;            // n_r - 1, n_s + 1 in lanes 2,3 (mod 4)
             const int dsgn_l = dq_l;                                              // -deg, +deg in the same lanes
-            const int odd_mask_l = (lane & 1u) ? -1 : 0;
-            const int eta_mask_l = (lane & 4u) ? -1 : 0;                          // lanes 4..7 (mod 8): the eta terms
+            int odd_mask_l = (lane & 1u) ? -1 : 0;
+            int eta_mask_l = (lane & 4u) ? -1 : 0;                                // lanes 4..7 (mod 8): the eta terms
+            __asm__ volatile("" : "+v"(odd_mask_l), "+v"(eta_mask_l));            // (opaque: stay bit operations on vector registers)
             const int toff_l = (lane & 4u) ? eoff_l : 1;                          // table index = argument + this
             int oth_mask_l = lane < k_oth ? -1 : 0;
             __asm__ volatile("" : "+v"(oth_mask_l));  // (opaque: stays an AND with a vector register)
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                 // (every lane reads and writes the same LDS words with the same values; the sum of accepted dS and the
                 // accepted count are bumped by lane 0 where a step is accepted)
                 auto book_min = [&](bool ok, double T) {
-                    if (track_min) {
+                    if (track_min != 0u) {
                         wfence();
                         const double c = *bk_cum;
                         if (ok && c < *bk_emin) {
