@@ -250,7 +250,10 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                         for (int u = 0; u < U; ++u) {
                             const bool on = j0 + u < my_deg;
                             const uint32_t id = on ? ids[lane * RS + j0 + u] : 0u;
-                            lab[u] = labels[id];  // unconditional load, idle lanes read node 0
+                            // unconditional load, idle lanes read node 0.  Non-temporal: a label byte is used once, and
+                            // streamed past the L1 it leaves the stepping waves' table lines alone (+3.5 % at four
+                            // chains per CU; streaming the row extents and the LDS-DMA rows as well measured -5 %)
+                            lab[u] = __builtin_nontemporal_load(labels + id);
                         }
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
