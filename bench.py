@@ -64,7 +64,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    # two untimed sweeps by default: the first launch of a process runs ~14 % slow (cold clocks / TLBs) and the second
+    # one sometimes still does (profiles/README.md)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--chains", type=int, default=1024, help="chains per GPU")
     ap.add_argument("--na", type=int, default=500_000)
     ap.add_argument("--nb", type=int, default=500_000)
@@ -127,6 +129,8 @@ def main():
     for _ in range(args.steps):
         mh.anneal(model, pkg.constant_schedule, [1.0], n, 1 << 60)  # blocks until the sweep kernel is done
         ms, upd = model.last_sweep_timing()
+        if os.environ.get("BISBM_BENCH_VERBOSE"):
+            print("launch %.1f ms" % ms, file=sys.stderr, flush=True)
         kernel_ms += ms
         updates += upd
     sync()
