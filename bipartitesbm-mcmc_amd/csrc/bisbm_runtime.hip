@@ -374,7 +374,8 @@ int bisbm_create(bisbm_handle* out, uint64_t n, uint64_t na, uint64_t nb, const 
 
     const size_t C = n_chains, K = h->K, D = (size_t)maxdeg + 1;
     CCHK(dalloc(&h->d_rowptr, n + 1));
-    CCHK(dalloc(&h->d_col, nnz));
+    CCHK(dalloc(&h->d_col, nnz + 4));  // four spare entries: the production kernel reads a row's ids 16 bytes at a time
+    CCHK(hipMemset(h->d_col, 0, sizeof(uint32_t) * (nnz + 4)));
     CCHK(dalloc(&h->d_labels, C * h->label_stride));
     CCHK(dalloc(&h->d_m, C * ka * kb));
     CCHK(dalloc(&h->d_m_r, C * K));

@@ -59,6 +59,15 @@ __device__ unsigned long long g_fast_stamps[16];
     do {          \
     } while (0)
 #endif
+// BISBM_STAMPS=2: only the two per-chunk stamps (time in the chunk's steps / time waiting for the feeder), so
+// that the step loop itself is the production code
+#if defined(BISBM_STAMPS) && BISBM_STAMPS == 2
+#define FSTAMP_STEP(i) \
+    do {               \
+    } while (0)
+#else
+#define FSTAMP_STEP(i) FSTAMP(i)
+#endif
 
 __device__ __forceinline__ void wfence() {
     __builtin_amdgcn_wave_barrier();
@@ -72,6 +81,10 @@ __device__ __forceinline__ double tab_at(const double* base, uint32_t idx) {
 #endif
     return *(const double*)((const char*)base + (uint32_t)(idx << 3));  // tables are < 2^28 entries (host check)
 }
+
+struct __attribute__((packed, aligned(4))) Id4 {  // four consecutive column ids, 4-byte aligned
+    uint32_t x, y, z, w;
+};
 
 constexpr uint32_t kHistStride = 68;  // bytes per k_v row: 64 counters + pad (17 dwords: odd, conflict-free)
 constexpr uint32_t kHandWords = 5;    // v, row begin, degree, own label, pivot label
@@ -91,18 +104,15 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t ka = p.ka, kb = p.kb, K = ka + kb, na = p.na, nb = p.nb;
     const uint32_t D = p.maxdeg + 1, S = kb | 1u;
-    const uint32_t row_cap = p.maxdeg < (uint32_t)kWave ? p.maxdeg : (uint32_t)kWave;  // staged ids per row
-    const uint32_t RS = row_cap | 1u;                                                   // ids row stride, dwords (odd)
+    const uint32_t row_cap = p.maxdeg < (uint32_t)kWave ? p.maxdeg : (uint32_t)kWave;  // neighbours walked per row by the feeder
     // LDS layout, dword offsets
     const uint32_t o_mq = 0, o_eta = ka * S;
-    const uint32_t o_ids = o_eta + (EL ? K * D : 0u);
-    const uint32_t o_hist8 = o_ids + kWave * RS;                             // two buffers of k_v rows
+    const uint32_t o_hist8 = o_eta + (EL ? K * D : 0u);                      // two buffers of k_v rows
     const uint32_t o_hand = o_hist8 + 2 * kWave * (kHistStride / 4);         // two hand-off buffers, kHandWords x 64 dwords
     const uint32_t o_slow = o_hand + 2 * kHandWords * kWave;
     const uint32_t o_flag = o_slow + kWave;
     int32_t* const mq = (int32_t*)(lds32 + o_mq);
     uint32_t* const eta_l = lds32 + o_eta;
-    uint32_t* const ids = lds32 + o_ids;
     uint32_t* const hist8_base = lds32 + o_hist8;           // k_v byte counters: 2 buffers x 64 rows
     uint32_t* const hand_base = lds32 + o_hand;             // per-chunk lane data handed from the feeder wave
     int32_t* const slow_hist = (int32_t*)(lds32 + o_slow);  // 64 counters for rows longer than 64
@@ -209,6 +219,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
             Feistel order;
             order.init(phx_draw(p.seed, chain_gid, PHX_SWEEP_KEY, 2 * sweeps_total + (TB ? 1 : 0)), n_own);
             const uint32_t n_chunks = (n_own + kWave - 1) / kWave;
+            const uint32_t node_other0 = TB ? 0u : na;  // some node of the opposite type: what idle slots of the walk load
 
             // ---- feeder wave: everything of chunk c that does not depend on the chain's block state ----
             auto prepare = [&](uint32_t c) {
@@ -226,41 +237,51 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     which_l = (uint32_t)(u53(A.x, A.y) * (double)deg_l);  // pivot neighbour, blockmodel.cc:619
                     if (which_l >= deg_l) which_l = deg_l ? deg_l - 1 : 0;
                 }
-                // CSR staging: the 64 rows (first row_cap ids each) HBM -> LDS by LDS-DMA, one row slot per
-                // instruction, all in flight together
-                wfence();
-                for (uint32_t q = 0; q < cnt; ++q) {
-                    const uint32_t b0 = readlane(beg_l, q), d0 = readlane(deg_l, q);
-                    if (lane < d0 && lane < row_cap)
-                        __builtin_amdgcn_global_load_lds(p.col + b0 + lane, ids + q * RS, 4, 0, 0);
-                }
-                // k_v rows: zero, then every lane walks its own row
+                // k_v rows: zero, then every lane walks its own adjacency row straight from HBM, 16 neighbours at a
+                // time: four 16-byte loads of ids (a lane's ids are contiguous; col[] carries four spare entries so the
+                // last row may be read past), 16 label gathers, 16 counter bumps.  No per-neighbour branches: idle
+                // slots load node 0 and add zero.
                 for (uint32_t w = 0; w < kHistStride / 4; ++w) hist8w[lane * (kHistStride / 4) + w] = 0;
-                __builtin_amdgcn_s_waitcnt(0);  // DMA writes have landed (vmcnt) before any ds_read of ids
                 wfence();
-                int piv_l = (int)oth_base;  // label of the pivot neighbour
+                const bool mine = lane < cnt && deg_l <= (uint32_t)kWave;  // longer rows: per-step side path
+#if defined(BISBM_ABLATE) && (BISBM_ABLATE & 64)
+                const uint32_t my_deg = 0u;  // diagnostic build: the feeder walks nothing, every k_v is zero (wrong results)
+#else
+                const uint32_t my_deg = mine ? deg_l : 0u;
+#endif
+                // the pivot neighbour's label (:619-620): two dependent loads, in flight during the walk
+                const int piv_l = (int)__builtin_nontemporal_load(labels + (my_deg ? p.col[beg_l + which_l] : node_other0));
                 {
-                    const bool mine = lane < cnt && deg_l <= (uint32_t)kWave;  // longer rows: per-step side path
-                    const uint32_t my_deg = mine ? deg_l : 0u;
                     constexpr int U = 16;
+                    const uint32_t row_byte0 = lane * kHistStride;
                     for (uint32_t j0 = 0; j0 < row_cap; j0 += U) {
                         if (__ballot(j0 < my_deg) == 0) break;
+                        uint32_t idv[U];
+#pragma unroll
+                        for (int u = 0; u < U; u += 4) {
+                            const Id4 v4 = *(const Id4*)(p.col + beg_l + j0 + u);
+                            idv[u + 0] = v4.x, idv[u + 1] = v4.y, idv[u + 2] = v4.z, idv[u + 3] = v4.w;
+                        }
                         int lab[U];
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
-                            const bool on = j0 + u < my_deg;
-                            const uint32_t id = on ? ids[lane * RS + j0 + u] : 0u;
-                            // unconditional load, idle lanes read node 0.  Non-temporal: a label byte is used once, and
-                            // streamed past the L1 it leaves the stepping waves' table lines alone (+3.5 % at four
-                            // chains per CU; streaming the row extents and the LDS-DMA rows as well measured -5 %)
-                            lab[u] = __builtin_nontemporal_load(labels + id);
+                            // Non-temporal: a label byte is used once, and streamed past the L1 it leaves the stepping
+                            // waves' table lines alone (+3.5 % at four chains per CU)
+#if defined(BISBM_ABLATE) && (BISBM_ABLATE & 256)
+                            lab[u] = (int)(oth_base + (idv[u] & 31u) % k_oth);  // diagnostic (with bit 8 only): no label gathers
+#else
+                            lab[u] = __builtin_nontemporal_load(labels + (j0 + u < my_deg ? idv[u] : node_other0));
+#endif
                         }
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
-                            const bool on = j0 + u < my_deg;
-                            const uint32_t byte = lane * kHistStride + (uint32_t)(lab[u] - (int)oth_base);
-                            if (on) atomicAdd(&hist8w[byte >> 2], 1u << ((byte & 3u) * 8u));
-                            if (on && j0 + u == which_l) piv_l = lab[u];
+                            const uint32_t byte = row_byte0 + (uint32_t)(lab[u] - (int)oth_base);
+                            const uint32_t one = j0 + u < my_deg ? 1u : 0u;
+#if defined(BISBM_ABLATE) && (BISBM_ABLATE & 128)
+                            if (byte == 0xffffffffu) hist8w[0] = one;  // diagnostic (with bit 8 only): no counter bumps
+#else
+                            atomicAdd(&hist8w[byte >> 2], one << ((byte & 3u) * 8u));
+#endif
                         }
                     }
                 }
@@ -478,7 +499,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                 // register, unless the early-stop bookkeeping is on (T < 1).
                 auto step = [&](uint32_t q) {
                     const double T = CT ? T_const : temperature_of(p, sweep_step0 + node_base + vi0 + q);  // :84
-                    FSTAMP(0);
+                    FSTAMP_STEP(0);
                     const uint32_t prop = readlane(prop_l, q);
                     if (__builtin_expect((int32_t)prop < 0 || (!CT && T == 0.), 0)) {
                         step_general(q, T);
@@ -498,13 +519,13 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     const double L1 = tab_at(tab.lg, (uint32_t)(m_rt + 1));
                     const double L3 = tab_at(tab.lg, (uint32_t)(m_rt + 1) - kk);
                     __asm__ volatile("" ::: "memory");  // keeps the loads above from being sunk below the r == s test
-                    FSTAMP(1);
+                    FSTAMP_STEP(1);
                     // integer inverse CDF (:627-628): first own block whose running total exceeds x.  Lanes past
                     // k_own hold garbage, but block k_own - 1 always qualifies (its total is m_r[t] > x).
                     const int scan = K32 ? wave_inclusive_scan32(w_piv) : wave_inclusive_scan(w_piv);
                     const unsigned long long hit = __builtin_amdgcn_ballot_w64((uint32_t)scan > prop) | last_own_bit;
                     const uint32_t s_loc = (uint32_t)__builtin_ctzll(hit);
-                    FSTAMP(2);
+                    FSTAMP_STEP(2);
                     if (s_loc == r_loc) {  // r == s: accepted as is (T > 0 here), nothing changes (:109-112)
                         book(n_r_r != 1, T);
                         return;
@@ -530,7 +551,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     const double logn = tab_at(tab.logtab, (uint32_t)qn);  // log(n) of the log_q arguments
                     const double L2 = tab_at(tab.lg, (uint32_t)(m_st + 1));
                     const double L4 = tab_at(tab.lg, (uint32_t)(m_st + 1) + kk);
-                    FSTAMP(3);
+                    FSTAMP_STEP(3);
                     // Hastings sums: on-chip data only, they run while the table gathers are in flight.
                     // k == 0 lanes give exact zeros (0 * x = +0, identical table entries cancel).
                     const double a0 = k * (m_st + eps) * inv_oth;
@@ -542,7 +563,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                         accu0 = butterfly_sum(a0);
                         accu1 = butterfly_sum(a1);
                     }
-                    FSTAMP(4);
+                    FSTAMP_STEP(4);
                     // log_q of the four (n, k) pairs, one per lane (mod 4).  Tier u = k / sqrt(n) > 24 above the table
                     // (k^2 > 576 n, evaluated in doubles: the tiers agree to 6e-16 around the boundary) is the closed
                     // form of bisbm_device.hpp (log_q_approx<true>) written out on pinned constants; anything else
@@ -560,12 +581,12 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                             lq = log_q<true>(tab, qn, qk, logn);
                         }
                     }
-                    FSTAMP(5);
+                    FSTAMP_STEP(5);
                     double d = (L1 + L2) - (L3 + L4);
                     d = d + tail_lg * sign_tail;  // scalar terms folded into leaves 0..7 / 0..3, see step_general
                     d = d + lq * sign_q;
                     const double dS = K32 ? butterfly_sum_low32(d) : butterfly_sum(d);
-                    FSTAMP(6);
+                    FSTAMP_STEP(6);
                     // accept (:47-61): u accu0 < accu1 exp(-dS/T), decided on a 1e-7-accurate exponential unless
                     // the two sides are within 1e-5 of each other (then the exact one decides)
                     const double z = -dS * (CT ? invT_const : 1.0 / T);
@@ -573,7 +594,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     const double lhs = readlane(ud_acc, q) * accu0;
                     const unsigned long long b_lt = __builtin_amdgcn_ballot_w64(lhs < est);
                     const unsigned long long b_far = __builtin_amdgcn_ballot_w64(fabs(lhs - est) > c_tol * est);
-                    FSTAMP(7);
+                    FSTAMP_STEP(7);
                     if ((b_lt | ~b_far) == 0) {  // clearly rejected
                         book_min(false, T);
                         return;
@@ -602,7 +623,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                         mq[a_st] = m_st + k;
                     }
                     wfence();
-                    FSTAMP(8);
+                    FSTAMP_STEP(8);
                     book_min(true, T);
                 };
                 for (uint32_t q = 0; q < cnt; ++q) step(q);
@@ -666,8 +687,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
 
 size_t sweep_fast_lds_bytes(uint32_t ka, uint32_t kb, uint32_t maxdeg, bool eta_in_lds) {
     const uint32_t K = ka + kb, D = maxdeg + 1, S = kb | 1u;
-    const uint32_t row_cap = maxdeg < (uint32_t)kWave ? maxdeg : (uint32_t)kWave, RS = row_cap | 1u;
-    const size_t dwords = (size_t)ka * S + (eta_in_lds ? (size_t)K * D : 0) + (size_t)kWave * RS +
+    const size_t dwords = (size_t)ka * S + (eta_in_lds ? (size_t)K * D : 0) +
                           2 * (size_t)kWave * (kHistStride / 4) + 2 * (size_t)kHandWords * kWave + kWave + 4 + 10;
     // the step reads m[.][lane] for all 64 lanes whatever ka, kb are (idle lanes are masked after the read):
     // dword index <= 63 * S + 63 must be inside the allocation
