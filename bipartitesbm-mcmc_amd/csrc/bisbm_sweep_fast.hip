@@ -8,9 +8,9 @@
 // A Philox-mode sweep visits all type-a nodes, then all type-b nodes, each class in a keyed
 // permutation (the two colour classes of the bipartite graph).  Inside a phase the visited nodes are
 // never neighbours of each other, so everything a step reads about its neighbourhood is frozen:
-//   * CSR and labels are consumed per 64 nodes, lane q <-> node q: the 64 adjacency rows are staged
-//     HBM -> LDS by LDS-DMA (all in flight together), then every lane walks ITS row, gathers the
-//     neighbour labels 16 at a time and counts them into its own row of k_v byte counters in LDS.
+//   * CSR and labels are consumed per 64 nodes, lane q <-> node q: every lane walks ITS adjacency row
+//     straight from HBM, 16 neighbours at a time (four 16-byte id loads, 16 label gathers, all in
+//     flight together), and counts the labels into its own row of k_v byte counters in LDS.
 //     Per step that leaves one LDS read for k_v; no label pipeline, no replay of moves;
 //   * m_r of the opposite type cannot change in the phase: 1/(m_r[t] + eps K) is a per-lane constant
 //     of the phase (no division per step); the code of a phase is specialised on the type (no
@@ -18,8 +18,8 @@
 //   * the pivot neighbour of the proposal depends only on the step's uniform and the row, so its label
 //     is picked up during the same walk.
 // Two waves per chain: wave 0 runs the steps, wave 1 ("feeder") prepares the NEXT chunk meanwhile --
-// visit order, row extents, own labels, LDS-DMA of the rows, the label walk into a second set of k_v
-// counters -- and hands it over through LDS at one workgroup barrier per chunk.  The memory latency of
+// visit order, row extents, own labels, the label walk into a second set of k_v counters, the pivot
+// neighbour's label -- and hands it over through LDS at one workgroup barrier per chunk.  The memory latency of
 // a chunk's preparation (several dependent HBM round trips) is thereby off the step path entirely.
 // State on chip: the a x b quadrant of m (odd row stride: rows and columns conflict-free) and eta in
 // LDS; m_r / n_r in registers (lane i <-> block i of each type).  dS and the Hastings sums are DPP
