@@ -258,8 +258,9 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                         if (__ballot(j0 < my_deg) == 0) break;
                         uint32_t idv[U];
 #pragma unroll
-                        for (int u = 0; u < U; u += 4) {
-                            const Id4 v4 = *(const Id4*)(p.col + beg_l + j0 + u);
+                        for (int u = 0; u < U; u += 4) {  // (only lanes whose row reaches this far: no sectors fetched for nothing)
+                            Id4 v4 = {0u, 0u, 0u, 0u};
+                            if (j0 + u < my_deg) v4 = *(const Id4*)(p.col + beg_l + j0 + u);
                             idv[u + 0] = v4.x, idv[u + 1] = v4.y, idv[u + 2] = v4.z, idv[u + 3] = v4.w;
                         }
                         int lab[U];
