@@ -481,7 +481,7 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
     double rate = 0.;
     bool stopped = false;
     for (uint64_t sweep = 0; sweep < all_sweeps; ++sweep) {
-        Feistel order_a, order_b;  // Philox mode: all type-a nodes, then all type-b nodes, each class permuted
+        TiledOrder order_a, order_b;  // Philox mode: all type-a nodes, then all type-b nodes, each class permuted
         if (RNG == RNG_COMPAT) {
             mt_shuffle(engine, vl, (uint32_t)num_nodes);  // :80
         } else {

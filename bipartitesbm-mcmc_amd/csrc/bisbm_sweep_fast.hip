@@ -5,8 +5,8 @@
 // chain per wavefront, persistent over all sweeps of the call.  Every number it produces is the one
 // the generic kernel (bisbm_kernels.hip, sweep_kernel<RNG_PHILOX>) produces; the tests run both.
 //
-// A Philox-mode sweep visits all type-a nodes, then all type-b nodes, each class in a keyed
-// permutation (the two colour classes of the bipartite graph).  Inside a phase the visited nodes are
+// A Philox-mode sweep visits all type-a nodes, then all type-b nodes, each class in a keyed, id-local
+// permutation (TiledOrder; the two colour classes of the bipartite graph).  Inside a phase the visited nodes are
 // never neighbours of each other, so everything a step reads about its neighbourhood is frozen:
 //   * CSR and labels are consumed per 64 nodes, lane q <-> node q: every lane walks ITS adjacency row
 //     straight from HBM, 16 neighbours at a time (four 16-byte id loads, 16 label gathers, all in
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
             const int toff_l = (lane & 4u) ? eoff_l : 1;                          // table index = argument + this
             int oth_mask_l = lane < k_oth ? -1 : 0;
             __asm__ volatile("" : "+v"(oth_mask_l));  // (opaque: stays an AND with a vector register)
-            Feistel order;
+            TiledOrder order;
             order.init(phx_draw(p.seed, chain_gid, PHX_SWEEP_KEY, 2 * sweeps_total + (TB ? 1 : 0)), n_own);
             const uint32_t n_chunks = (n_own + kWave - 1) / kWave;
             const uint32_t node_other0 = TB ? 0u : na;  // some node of the opposite type: what idle slots of the walk load
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                 const uint32_t my_deg = mine ? deg_l : 0u;
 #endif
                 // the pivot neighbour's label (:619-620): two dependent loads, in flight during the walk
-                const int piv_l = (int)__builtin_nontemporal_load(labels + (my_deg ? p.col[beg_l + which_l] : node_other0));
+                const int piv_l = (int)labels[my_deg ? p.col[beg_l + which_l] : node_other0];
                 {
                     constexpr int U = 16;
                     const uint32_t row_byte0 = lane * kHistStride;
@@ -266,12 +266,13 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                         int lab[U];
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
-                            // Non-temporal: a label byte is used once, and streamed past the L1 it leaves the stepping
-                            // waves' table lines alone (+3.5 % at four chains per CU)
 #if defined(BISBM_ABLATE) && (BISBM_ABLATE & 256)
                             lab[u] = (int)(oth_base + (idv[u] & 31u) % k_oth);  // diagnostic (with bit 8 only): no label gathers
 #else
-                            lab[u] = __builtin_nontemporal_load(labels + (j0 + u < my_deg ? idv[u] : node_other0));
+                            // (plain cached loads: with the id-local visit order the label sectors are re-used by the
+                            // following nodes out of the L2 -- non-temporal loads, +3.5 % under the old scattered
+                            // order, cost 5 % here)
+                            lab[u] = labels[j0 + u < my_deg ? idv[u] : node_other0];
 #endif
                         }
 #pragma unroll

@@ -403,6 +403,20 @@ static uint32_t feistel_perm(const uint32_t keys[4], uint32_t n, uint32_t i) {
     return x;
 }
 
+/* Visit order of a Philox-mode phase: tiles of 4096 consecutive ids in a keyed order, the ids of a tile in a keyed
+ * order of their own (local in node ids: consecutive steps gather labels from the same neighbourhoods), cycle
+ * walking over the padded domain. */
+static uint32_t tiled_perm(const uint32_t keys[4], uint32_t n, uint32_t i) {
+    const uint32_t ntiles = (n + 4095u) >> 12;
+    uint32_t x = i;
+    do {
+        uint32_t t = feistel_perm(keys, ntiles, x >> 12);
+        uint32_t k2[4] = {keys[1] ^ (t * 0x9E3779B9u), keys[2], keys[3], keys[0]};
+        x = (t << 12) | feistel_perm(k2, 4096u, x & 4095u);
+    } while (x >= n);
+    return x;
+}
+
 /* Philox-mode visit order of one sweep: first every type-a node, then every type-b node (the two colour
  * classes of the bipartite graph: within a phase no visited node is a neighbour of another, so the
  * neighbour labels a step reads are frozen for the whole phase), each class in its own keyed
@@ -411,10 +425,10 @@ uint32_t orc_philox_visit(uint64_t seed, uint32_t chain, uint64_t sweep, uint32_
     uint32_t keys[4];
     if (i < na) {
         phx_draw(seed, chain, PHX_SWEEP_KEY, 2 * sweep, keys);
-        return feistel_perm(keys, na, i);
+        return tiled_perm(keys, na, i);
     }
     phx_draw(seed, chain, PHX_SWEEP_KEY, 2 * sweep + 1, keys);
-    return na + feistel_perm(keys, nb, i - na);
+    return na + tiled_perm(keys, nb, i - na);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1068,8 +1082,8 @@ double orc_anneal(orc_model *m, int schedule, float kw0, float kw1, uint64_t dur
             if (m->rng_mode == ORC_RNG_COMPAT)
                 ok = step_compat(m, m->vlist[vi], temperature);
             else {
-                size_t v = vi < m->na ? feistel_perm(keys_a, (uint32_t)m->na, (uint32_t)vi)
-                                      : m->na + feistel_perm(keys_b, (uint32_t)m->nb, (uint32_t)(vi - m->na));
+                size_t v = vi < m->na ? tiled_perm(keys_a, (uint32_t)m->na, (uint32_t)vi)
+                                      : m->na + tiled_perm(keys_b, (uint32_t)m->nb, (uint32_t)(vi - m->na));
                 ok = step_philox(m, v, temperature, m->sweeps_total * num_nodes + vi);
             }
             if (ok) {
