@@ -403,16 +403,18 @@ static uint32_t feistel_perm(const uint32_t keys[4], uint32_t n, uint32_t i) {
     return x;
 }
 
-/* Visit order of a Philox-mode phase: tiles of 4096 consecutive ids in a keyed order, the ids of a tile in a keyed
- * order of their own (local in node ids: consecutive steps gather labels from the same neighbourhoods), cycle
- * walking over the padded domain. */
+/* Visit order of a Philox-mode phase, local in node ids: tiles of 4096 consecutive ids in a keyed order, inside a
+ * tile its 64 cells of 64 ids in a keyed order, inside a cell the ids in a keyed order (consecutive steps gather
+ * labels from the same neighbourhoods and read adjacent CSR rows); cycle walking over the padded domain. */
 static uint32_t tiled_perm(const uint32_t keys[4], uint32_t n, uint32_t i) {
     const uint32_t ntiles = (n + 4095u) >> 12;
     uint32_t x = i;
     do {
         uint32_t t = feistel_perm(keys, ntiles, x >> 12);
         uint32_t k2[4] = {keys[1] ^ (t * 0x9E3779B9u), keys[2], keys[3], keys[0]};
-        x = (t << 12) | feistel_perm(k2, 4096u, x & 4095u);
+        uint32_t c = feistel_perm(k2, 64u, (x >> 6) & 63u);
+        uint32_t k3[4] = {keys[2] ^ (((t << 6) | c) * 0x85EBCA6Bu), keys[3], keys[0], keys[1]};
+        x = (t << 12) | (c << 6) | feistel_perm(k3, 64u, x & 63u);
     } while (x >= n);
     return x;
 }
