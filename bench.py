@@ -64,8 +64,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    # two untimed sweeps by default: right after the randomised start most proposals are accepted (apply path), the
-    # first two sweeps run 15-20 % slower than the following ones (profiles/README.md)
+    # two untimed sweeps by default: the first one or two launches of a process run 15-20 % slower than the following
+    # ones (the device leaving its idle power state, about 2 s of load; profiles/README.md)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--chains", type=int, default=1024, help="chains per GPU")
     ap.add_argument("--na", type=int, default=500_000)
