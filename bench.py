@@ -64,9 +64,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    # two untimed sweeps by default: the first one or two launches of a process run 15-20 % slower than the following
-    # ones (the device leaving its idle power state, about 2 s of load; profiles/README.md)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spinup", type=int, default=2, help="throw-away sweeps before the warm-up (device power state)")
     ap.add_argument("--chains", type=int, default=1024, help="chains per GPU")
     ap.add_argument("--na", type=int, default=500_000)
     ap.add_argument("--nb", type=int, default=500_000)
@@ -121,6 +120,14 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # Device spin-up, not part of the protocol's W + K steps: the first ~2 s of load after a process starts run 15-20 %
+    # slow (idle power state).  Two throw-away sweeps, then the chains are put back on a fresh randomised start, so the
+    # warm-up and timed sweeps below are the first sweeps of their chains whatever W is.
+    for _ in range(args.spinup):
+        mh.anneal(model, pkg.constant_schedule, [1.0], n, 1 << 60)
+    if args.spinup:
+        model.set_memberships(labels)
+        model.shuffle_bisbm()
     for _ in range(args.warmup):
         mh.anneal(model, pkg.constant_schedule, [1.0], n, 1 << 60)
     sync()
@@ -187,6 +194,7 @@ def main():
                 + "planted bipartite N_a=%d N_b=%d E=%d Ka=%d Kb=%d, %d chains/GPU, constant T=1, eps=1, "
                   "randomised start, Philox mode" % (na, nb, E, ka, kb, args.chains),
                 "chains_total": args.chains * world, "step": "one sweep (n node updates) of every chain",
+                "spinup_sweeps_before_warmup": args.spinup,
                 "parallelism": "chains sharded, no collective in the sweep path",
             },
             "roofline": {
