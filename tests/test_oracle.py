@@ -217,6 +217,17 @@ def test_philox_kat_and_visit_order():
     a = [L.orc_philox_visit(7, 3, 11, 500, 500, i) for i in range(1000)]
     b = [L.orc_philox_visit(7, 3, 12, 500, 500, i) for i in range(1000)]
     assert a != b
+    # the order is local in node ids: 64 consecutive positions visit one cell of 64 consecutive ids, 4096 consecutive
+    # positions one tile of 4096 ids (up to the cycle-walked tail of a class that is not a multiple of 4096)
+    na = 3 * 4096 + 700
+    p = np.array([L.orc_philox_visit(99, 0, 5, na, 64, i) for i in range(na)])
+    assert sorted(p) == list(range(na))
+    full = p[: 3 * 4096].reshape(-1, 64)
+    inside = [(c // 64 == c[0] // 64).all() for c in full]          # cells stay together ...
+    assert sum(inside) >= len(full) - 16                            # ... except where the padded tail walks in
+    tiles = p[: 3 * 4096].reshape(-1, 4096) // 4096
+    assert all(np.bincount(t).max() >= 4096 - 64 * 12 for t in tiles)
+    assert len({int(np.bincount(t).argmax()) for t in tiles}) == 3  # and the tiles come in a permuted order
 
 
 # ------------------------------------------------------------------ libstdc++ 11, draw for draw
