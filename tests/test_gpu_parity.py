@@ -153,6 +153,29 @@ def test_matches_oracle(case, mode):
     assert g.entropy()[0] == pytest.approx(o.entropy(), rel=1e-9)
 
 
+def test_hot_step_many_chains_philox():
+    """The production kernel's hot step (closed-form log_q tier) with several chains per launch: every chain equals
+    its own oracle run (chain ids key the streams, workgroup <-> chain mapping, per-chain state in LDS)."""
+    name, na, nb, ne, ka, kb, eps, hubs, iso = next(c for c in CASES if c[0] == "direct_tier")
+    rowptr, col = _random_graph(11, na, nb, ne, ka, kb, hubs, iso)
+    labels = O.contiguous_labels(na, nb, ka, kb)
+    n, chains, first = na + nb, 12, 40
+    g = gpu_model(rowptr, col, na, nb, ka, kb, eps, labels, n_chains=chains, rng="philox", seed=5150, first_chain_id=first)
+    g.shuffle_bisbm()
+    mh = B.MetropolisHasting()
+    rates = mh.anneal(g, "constant", [1.0], 2 * n, BIG)
+    rates2 = mh.anneal(g, "exponential", [2.0, 0.99995], 2 * n, BIG)
+    cum = g.get_entropy()
+    for c in range(chains):
+        o = O.OracleModel(rowptr, col, na, nb, ka, kb, eps, labels)
+        o.seed_philox(5150, first + c)
+        o.shuffle_bisbm()
+        assert o.anneal("constant", [1.0], 2 * n, BIG) == rates[c]
+        assert o.anneal("exponential", [2.0, 0.99995], 2 * n, BIG) == rates2[c]
+        assert_state_equal(g, o, c)
+        assert cum[c] == pytest.approx(o.get_entropy(), rel=1e-9)
+
+
 def test_config2_256_chains_philox():
     """BASELINE config 2: n_1000, Ka=4, Kb=6, 256 independent chains, constant T=1."""
     rowptr, col, na, nb = O.load_graph("n_1000")
