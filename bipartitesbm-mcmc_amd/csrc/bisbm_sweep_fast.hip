@@ -117,13 +117,11 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     uint32_t* const hand_base = lds32 + o_hand;             // per-chunk lane data handed from the feeder wave
     int32_t* const slow_hist = (int32_t*)(lds32 + o_slow);  // 64 counters for rows longer than 64
     uint32_t* const stop_flag = lds32 + o_flag;
-    // anneal()'s running numbers live in LDS, not in registers: most steps do not touch them at all, and as
-    // loop-carried registers they cost a set of copies on every path of the step loop
+    // anneal()'s early-stop numbers live in LDS, not in registers: most runs do not touch them at all, and as
+    // loop-carried scalar registers they cost a set of copies on every path of the step loop
     const uint32_t o_books = (o_flag + 4u + 1u) & ~1u;
-    double* const bk_cum = (double*)(lds32 + o_books);            // blockmodel_t::entropy_, running sum of accepted dS
     double* const bk_emin = (double*)(lds32 + o_books + 2);       // entropy_min_ (metropolis_hasting.cc:75)
     unsigned long long* const bk_u = (unsigned long long*)(lds32 + o_books + 4);    // steps below T = 1 since the last minimum
-    unsigned long long* const bk_acc = (unsigned long long*)(lds32 + o_books + 6);  // accepted steps of this call
     const bool is_main = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;  // wave 0 steps, wave 1 feeds
 
     uint8_t* const labels = p.labels + (size_t)chain * p.label_stride;
@@ -141,10 +139,8 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
             for (uint32_t i = lane; i < K * D; i += kWave) eta_l[i] = eta_g[i];
         if (lane == 0) {
             *stop_flag = 0;
-            *bk_cum = sc->cum_dS;
             *bk_emin = INFINITY;  // metropolis_hasting.cc:75
             *bk_u = 0;
-            *bk_acc = 0;
         }
     }
     // The stepping wave shares its SIMD with the feeder wave of another chain (four chains per CU): it is the
@@ -181,6 +177,10 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     __asm__ volatile("" : "+v"(lqc.nc0l2e), "+v"(lqc.c1c0), "+v"(lqc.c1), "+v"(lqc.c2c0), "+v"(lqc.lfc));
     BISBM_PIN(c_576, 576.0);                       // 24^2: tier test k^2 > 576 n
     uint64_t sweeps_done = 0;
+    // Sum of accepted dS (blockmodel_t::entropy_) and accepted count: lane 0's copy is the value.  They are bumped
+    // inside the lane-0 region of an accepted step (a vector add under the execution mask, no LDS round trip).
+    double cum_l0 = sc->cum_dS;
+    unsigned long long acc_l0 = 0;
     double rate = 0.;
     bool stopped = false;
 #ifdef BISBM_STAMPS
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                 auto book_min = [&](bool ok, double T) {
                     if (track_min != 0u) {
                         wfence();
-                        const double c = *bk_cum;
+                        const double c = readlane(cum_l0, 0u);
                         if (ok && c < *bk_emin) {
                             *bk_emin = c;
                             *bk_u = 0;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     }
                 };
                 auto book = [&](bool ok, double T) {
-                    if (ok && lane == 0) atomicAdd(bk_acc, 1ull);
+                    if (ok && lane == 0) acc_l0 += 1;
                     book_min(ok, T);
                 };
 
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                             mq[a_rt] = m_rt - k;
                             mq[a_st] = m_st + k;
                         }
-                        if (lane == 0) atomicAdd(bk_cum, dS);  // :500
+                        if (lane == 0) cum_l0 += dS;  // :500
                         wfence();
                     }
                     book(ok, T);
@@ -614,8 +614,8 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                         eta_wr(r * D + deg, (uint32_t)(eta_r - 1));
                         eta_wr(s * D + deg, (uint32_t)(eta_s + 1));
                         labels[v] = (uint8_t)s;
-                        atomicAdd(bk_cum, dS);  // :500
-                        atomicAdd(bk_acc, 1ull);
+                        cum_l0 += dS;  // :500
+                        acc_l0 += 1;
                     }
                     const int dl = (int)min(lane ^ r_loc, 1u) - (int)min(lane ^ s_loc, 1u);  // +1 on lane s_loc, -1 on r_loc
                     mr_own += __mul24(ideg, dl);
@@ -653,12 +653,12 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
         if (is_main && lane == 0 && *bk_u >= p.steps_await) *stop_flag = 1;  // metropolis_hasting.cc:96-98
         __syncthreads();
         if (__builtin_amdgcn_readfirstlane((int)*stop_flag)) {  // (scalar: the sweep loop has no divergent exit)
-            rate = (double)*bk_acc / (double)((sweep + 1) * (uint64_t)n);
+            rate = (double)acc_l0 / (double)((sweep + 1) * (uint64_t)n);
             stopped = true;
             break;
         }
     }
-    if (!stopped) rate = (double)*bk_acc / (double)p.duration;  // :100
+    if (!stopped) rate = (double)acc_l0 / (double)p.duration;  // :100
 
     // chain state -> HBM (wave 0)
     __syncthreads();
@@ -679,10 +679,10 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
         for (int i = 0; i < 12; ++i) atomicAdd(&g_fast_stamps[i], st_acc[i]);
 #endif
     if (lane == 0) {
-        sc->cum_dS = *bk_cum;
+        sc->cum_dS = cum_l0;
         sc->sweeps_total = sweeps_total;
         sc->last_rate = rate;
-        sc->last_accepted = *bk_acc;
+        sc->last_accepted = acc_l0;
         sc->last_sweeps = sweeps_done;
     }
 }
