@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spinup", type=int, default=2, help="throw-away sweeps before the warm-up (device power state)")
+    ap.add_argument("--spinup", type=int, default=2, help="throw-away sweeps before the warm-up (device spin-up)")
     ap.add_argument("--chains", type=int, default=1024, help="chains per GPU")
     ap.add_argument("--na", type=int, default=500_000)
     ap.add_argument("--nb", type=int, default=500_000)
@@ -120,24 +120,32 @@ def main():
         if world > 1:
             dist.barrier()
 
-    # Device spin-up, not part of the protocol's W + K steps: the first ~2 s of load after a process starts run 15-20 %
-    # slow (idle power state).  Two throw-away sweeps, then the chains are put back on a fresh randomised start, so the
-    # warm-up and timed sweeps below are the first sweeps of their chains whatever W is.
+    # Device spin-up, not part of the protocol's W + K steps: in some processes one or two launches during the first
+    # seconds of load run 15-20 % slow (same seeds, same work).  Two throw-away sweeps, then the
+    # chains are put back on a fresh randomised start, so the warm-up and timed sweeps below are the first sweeps of
+    # their chains whatever W is.
+    verbose = bool(os.environ.get("BISBM_BENCH_VERBOSE"))
+
+    def note(what):
+        if verbose:
+            print("%s launch %.1f ms" % (what, model.last_sweep_timing()[0]), file=sys.stderr, flush=True)
+
     for _ in range(args.spinup):
         mh.anneal(model, pkg.constant_schedule, [1.0], n, 1 << 60)
+        note("spin-up")
     if args.spinup:
         model.set_memberships(labels)
         model.shuffle_bisbm()
     for _ in range(args.warmup):
         mh.anneal(model, pkg.constant_schedule, [1.0], n, 1 << 60)
+        note("warm-up")
     sync()
     t0 = time.perf_counter()
     kernel_ms, updates = 0.0, 0
     for _ in range(args.steps):
         mh.anneal(model, pkg.constant_schedule, [1.0], n, 1 << 60)  # blocks until the sweep kernel is done
         ms, upd = model.last_sweep_timing()
-        if os.environ.get("BISBM_BENCH_VERBOSE"):
-            print("launch %.1f ms" % ms, file=sys.stderr, flush=True)
+        note("timed")
         kernel_ms += ms
         updates += upd
     sync()

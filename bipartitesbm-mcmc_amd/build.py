@@ -21,7 +21,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          # loop-carried register on every path (~40 issue slots per step); told to leave uniform regions alone it
          # emits the branches as written and updates the block state in place.
          "-mllvm", "-structurizecfg-skip-uniform-regions=true",
-         # single-lane LDS atomics (sum of accepted dS, accepted count) stay single instructions
+         # single-lane LDS atomics (the early-stop bookkeeping below T = 1) stay single instructions
          "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 

@@ -117,6 +117,8 @@ CASES = [
     ("direct_tier_wide", 72000, 72000, 216000, 40, 33, 1.0, 0, 0),
     # ... and k / sqrt(n) around 23: the hot step falls back to the iterated / literal log_q tiers
     ("mid_tier", 5300, 5300, 26500, 2, 2, 1.0, 0, 0),
+    # no edges at all: every node has degree 0 (uniform proposals over all K blocks, blockmodel.cc:616-617)
+    ("edgeless", 10, 8, 0, 2, 2, 1.0, 0, 0),
 ]
 
 
@@ -142,7 +144,8 @@ def test_matches_oracle(case, mode):
     # (the linear ramp ends at T = 0.5: below zero the reference accepts cross-type proposals -- a = -dS/T = +inf,
     # metropolis_hasting.cc:55-57 -- and corrupts its own state; the engine never does, see DESIGN.md "hazards")
     for sched, kw, dur, await_ in [("constant", [1.0], 6 * n, BIG), ("linear", [2.0, 1.5 / (3 * n)], 3 * n, BIG),
-                                   ("abrupt_cool", [float(n)], 4 * n, BIG), ("exponential", [3.0, 0.999], 3 * n, 2 * n)]:
+                                   ("abrupt_cool", [float(n)], 4 * n, BIG), ("exponential", [3.0, 0.999], 3 * n, 2 * n),
+                                   ("logarithmic", [1.0, 2.0], 2 * n, BIG)]:
         ro = o.anneal(sched, kw, dur, await_)
         rg = mh.anneal(g, sched, kw, dur, await_)
         assert rg == ro, (sched, rg, ro)
