@@ -214,8 +214,6 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
             int eta_mask_l = (lane & 4u) ? -1 : 0;                                // lanes 4..7 (mod 8): the eta terms
             __asm__ volatile("" : "+v"(odd_mask_l), "+v"(eta_mask_l));            // (opaque: stay bit operations on vector registers)
             const int toff_l = (lane & 4u) ? eoff_l : 1;                          // table index = argument + this
-            int oth_mask_l = lane < k_oth ? -1 : 0;
-            __asm__ volatile("" : "+v"(oth_mask_l));  // (opaque: stays an AND with a vector register)
             TiledOrder order;
             order.init(phx_draw(p.seed, chain_gid, PHX_SWEEP_KEY, 2 * sweeps_total + (TB ? 1 : 0)), n_own);
             const uint32_t n_chunks = (n_own + kWave - 1) / kWave;
@@ -516,7 +514,11 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     const int w_piv = mq[mq_at(lane, t_loc)];
                     const int n_r_r = readlane(nr_own, r_loc);
                     // the two lgamma gathers that only need row r go out now: their latency runs under the proposal
-                    const int32_t m_rt = m_rt_raw & oth_mask_l;  // idle lanes: 0
+                    // Lanes with k == 0 (idle lanes included) contribute exact zeros to all three sums whatever m is, so
+                    // they all read table entry 1: a gather costs per distinct address, not per lane
+                    // (tools/probe/gather_lanes.hip), and a node touches only a few of the blocks.
+                    const int32_t kmask = (0 - k) >> 31;
+                    const int32_t m_rt = m_rt_raw & kmask;
                     const uint32_t kk = (uint32_t)k;
                     const double L1 = tab_at(tab.lg, (uint32_t)(m_rt + 1));
                     const double L3 = tab_at(tab.lg, (uint32_t)(m_rt + 1) - kk);
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     const int32_t m_st_raw = mq[a_st];
                     const int eta_r = (int)eta_rd(r * D + deg);
                     const int eta_s = (int)eta_rd(s * D + deg);
-                    const int32_t m_st = m_st_raw & oth_mask_l;  // idle lanes: 0
+                    const int32_t m_st = m_st_raw & kmask;
                     const int m0r = readlane(mr_own, r_loc);
                     const int m0s = readlane(mr_own, s_loc);
                     const int n_r_s = readlane(nr_own, s_loc);
@@ -621,8 +623,8 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     mr_own += __mul24(ideg, dl);
                     nr_own += dl;
                     if (lane < k_oth) {  // k == 0: rewrites the same values
-                        mq[a_rt] = m_rt - k;
-                        mq[a_st] = m_st + k;
+                        mq[a_rt] = m_rt_raw - k;
+                        mq[a_st] = m_st_raw + k;
                     }
                     wfence();
                     FSTAMP_STEP(8);
