@@ -21,6 +21,11 @@ struct ChainScalars {
     uint32_t engine_idx;     // std::mt19937 positions (compat mode)
     uint32_t gen_idx;
     uint32_t merge_epoch;  // Philox counter: proposal rounds of agg_merge so far
+    // where the last production sweep launch ran this chain: HW_ID of the stepping and of the feeder wave, XCC_ID
+    // (diagnostic, see BISBM_PLACEMENT_LOG in bisbm_runtime.hip)
+    uint32_t hw_id[2];
+    uint32_t xcc_id;
+    uint32_t pad_;
 };
 
 struct SweepParams {
@@ -57,7 +62,11 @@ struct SweepParams {
     uint64_t seed;
     int eta_in_lds;
     int vlist_in_lds;
+    // production kernel: one counter per SIMD of the chip (kSimdClaims entries, zeroed before the launch) through which
+    // the workgroups keep their stepping waves on different SIMDs; NULL: wave 0 steps
+    uint32_t* simd_claims;
 };
+constexpr uint32_t kSimdClaims = 1u << 14;  // index: XCC_ID[3:0] | HW_ID se, sh, cu [15:8] | simd [5:4]
 
 struct BuildParams {
     const uint32_t* rowptr;

@@ -195,6 +195,7 @@ struct bisbm_engine {
     int32_t* d_n_r = nullptr;
     uint32_t* d_eta = nullptr;
     ChainScalars* d_scalars = nullptr;
+    uint32_t* d_simd_claims = nullptr;  // production kernel: stepping-wave claims per SIMD, zeroed before every launch
     uint32_t* d_mt_engine = nullptr;
     uint32_t* d_mt_gen = nullptr;
     double* d_lgamma = nullptr;
@@ -245,7 +246,8 @@ void free_all(bisbm_engine* h) {
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->d_rowptr, h->d_col,       h->d_labels, h->d_labels_tmp, h->d_vlist,     h->d_m,
                     h->d_m_r,    h->d_n_r,       h->d_eta,    h->d_scalars,    h->d_mt_engine, h->d_mt_gen,
-                    h->d_lgamma, h->d_logtab, h->d_q,         h->d_T,      h->d_tmp_f64,    h->d_stage_u32, h->d_counts};
+                    h->d_lgamma, h->d_logtab, h->d_q,         h->d_T,      h->d_tmp_f64,    h->d_stage_u32, h->d_counts,
+                    h->d_simd_claims};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -605,6 +607,15 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     }
     if (lds > 160 * 1024) return fail(h, BISBM_ERR_UNSUPPORTED, "chain state needs %zu B of LDS (> 160 KiB)", lds);
 
+    p.simd_claims = nullptr;
+    if (fast) {
+        const char* fixed = getenv("BISBM_FIXED_ROLES");  // =1: wave 0 always steps (A/B checks)
+        if (!(fixed && fixed[0] == '1')) {
+            if (!h->d_simd_claims) HIPCHK(h, dalloc(&h->d_simd_claims, kSimdClaims));
+            HIPCHK(h, hipMemsetAsync(h->d_simd_claims, 0, sizeof(uint32_t) * kSimdClaims, h->stream));
+            p.simd_claims = h->d_simd_claims;
+        }
+    }
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     if (fast)
         HIPCHK(h, launch_sweep_fast(p, lds, h->stream));
@@ -624,6 +635,27 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
         updates += sc[c].last_sweeps * h->n;
     }
     h->last_updates = updates;
+    // BISBM_PLACEMENT_LOG=1 (diagnostic): how the dispatcher spread the launch over the chip.  A SIMD that hosts
+    // the stepping waves of two chains runs both of them slower, and the launch takes as long as its slowest chain.
+    if (fast) {
+        const char* plog = getenv("BISBM_PLACEMENT_LOG");
+        if (plog && plog[0] == '1') {
+            std::map<uint32_t, int> main_per_simd, wg_per_cu;
+            for (uint32_t c = 0; c < h->n_chains; ++c) {
+                const uint32_t hw = sc[c].hw_id[0], cu = ((sc[c].xcc_id & 0xf) << 16) | (hw & 0xff00u);  // se, sh, cu ids
+                ++main_per_simd[(cu << 2) | ((hw >> 4) & 3u)];
+                ++wg_per_cu[cu];
+            }
+            int simd_hist[5] = {0, 0, 0, 0, 0}, cu_hist[9] = {0};
+            for (auto& kv : main_per_simd) ++simd_hist[std::min(kv.second, 4)];
+            for (auto& kv : wg_per_cu) ++cu_hist[std::min(kv.second, 8)];
+            fprintf(stderr, "[bisbm placement] %.1f ms; CUs used %zu; workgroups per CU:", ms, wg_per_cu.size());
+            for (int i = 1; i <= 8; ++i)
+                if (cu_hist[i]) fprintf(stderr, " %dx%d", cu_hist[i], i);
+            fprintf(stderr, "; stepping waves per SIMD: %d x1, %d x2, %d x3, %d x4+\n", simd_hist[1], simd_hist[2],
+                    simd_hist[3], simd_hist[4]);
+        }
+    }
     return BISBM_OK;
 }
 

@@ -122,7 +122,33 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     const uint32_t o_books = (o_flag + 4u + 1u) & ~1u;
     double* const bk_emin = (double*)(lds32 + o_books + 2);       // entropy_min_ (metropolis_hasting.cc:75)
     unsigned long long* const bk_u = (unsigned long long*)(lds32 + o_books + 4);    // steps below T = 1 since the last minimum
-    const bool is_main = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;  // wave 0 steps, wave 1 feeds
+    // Which of the two waves steps and which feeds.  The dispatcher puts the two waves of a workgroup on different
+    // SIMDs and, with four workgroups per CU, two waves on every SIMD -- but not always one wave 0 and one wave 1: now
+    // and then a SIMD gets the wave 0 of two workgroups.  Two stepping waves on one SIMD run ~20 % slower each, and a
+    // launch lasts as long as its slowest chain (one such SIMD on the chip: 0.73 s -> 0.89 s per sweep, measured).  So
+    // the workgroup claims a SIMD for its stepping wave in a chip-wide table: wave 0's if that SIMD has no stepping
+    // wave yet, else wave 1's.  The roles are symmetric: results do not depend on the choice.
+    const uint32_t wave_in_wg = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t hw_id, xcc_id;
+    __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    uint32_t* const role = lds32 + o_flag + 1;  // [0], [1]: the waves' SIMD slots; [2]: the wave that steps
+    if (lane == 0) role[wave_in_wg] = ((xcc_id & 0xfu) << 10) | ((hw_id >> 6) & 0x3fcu) | ((hw_id >> 4) & 3u);
+    __syncthreads();
+    if (wave_in_wg == 0 && lane == 0) {
+        uint32_t pick = 0;
+        if (p.simd_claims != nullptr && atomicAdd(&p.simd_claims[role[0]], 1u) != 0u) {
+            if (atomicAdd(&p.simd_claims[role[1]], 1u) == 0u) {
+                pick = 1;
+                atomicSub(&p.simd_claims[role[0]], 1u);
+            } else {
+                atomicSub(&p.simd_claims[role[1]], 1u);  // both taken: stay with wave 0
+            }
+        }
+        role[2] = pick;
+    }
+    __syncthreads();
+    const bool is_main = (uint32_t)__builtin_amdgcn_readfirstlane((int)role[2]) == wave_in_wg;
 
     uint8_t* const labels = p.labels + (size_t)chain * p.label_stride;
     int32_t* const m_g = p.m + (size_t)chain * ka * kb;
@@ -131,6 +157,10 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     uint32_t* const eta_g = p.eta + (size_t)chain * K * D;
     ChainScalars* const sc = p.scalars + chain;
     const Tables tab{p.lgamma_tab, p.lgamma_size, p.q_tab, p.q_stride, p.log_tab};
+    if (lane == 0) {  // placement record: which SIMD of which CU the two waves landed on
+        sc->hw_id[is_main ? 0 : 1] = hw_id;
+        if (is_main) sc->xcc_id = xcc_id;
+    }
 
     // chain state -> LDS / registers (wave 0 owns it)
     if (is_main) {
@@ -340,18 +370,19 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                 // anneal()'s bookkeeping after a step, metropolis_hasting.cc:85-94
                 // (every lane reads and writes the same LDS words with the same values; the sum of accepted dS and the
                 // accepted count are bumped by lane 0 where a step is accepted)
-                auto book_min = [&](bool ok, double T) {
-                    if (track_min != 0u) {
-                        wfence();
-                        const double c = readlane(cum_l0, 0u);
-                        if (ok && c < *bk_emin) {
-                            *bk_emin = c;
-                            *bk_u = 0;
-                        }
-                        wfence();
-                        if (T < 1.) *bk_u = *bk_u + 1;
-                        wfence();
+                auto book_min_on = [&](bool ok, double T) {
+                    wfence();
+                    const double c = readlane(cum_l0, 0u);
+                    if (ok && c < *bk_emin) {
+                        *bk_emin = c;
+                        *bk_u = 0;
                     }
+                    wfence();
+                    if (T < 1.) *bk_u = *bk_u + 1;
+                    wfence();
+                };
+                auto book_min = [&](bool ok, double T) {
+                    if (track_min != 0u) book_min_on(ok, T);
                 };
                 auto book = [&](bool ok, double T) {
                     if (ok && lane == 0) acc_l0 += 1;
@@ -492,12 +523,15 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                 };
 
                 // ---- the 64 steps.  Hot path: 1 <= deg <= 64, target drawn from column m[.][t], T > 0 ----
-                const unsigned long long last_own_bit = 1ull << (k_own - 1);
+                const uint32_t last_own = k_own - 1;
                 const double invT_const = 1.0 / T_const;
                 // One step.  Early returns only (each is a jump to the loop latch); the rare cases leave through
                 // step_general at the top, before anything is computed.  A rejected step changes nothing, not even a
                 // register, unless the early-stop bookkeeping is on (T < 1).
-                auto step = [&](uint32_t q) {
+                // (tm: whether the early-stop bookkeeping is on, as a type -- the loop exists once per value, so the
+                // steps of a T >= 1 run carry no test of it)
+                auto step = [&](auto tm, uint32_t q) {
+                    constexpr bool TM = decltype(tm)::value;
                     const double T = CT ? T_const : temperature_of(p, sweep_step0 + node_base + vi0 + q);  // :84
                     FSTAMP_STEP(0);
                     const uint32_t prop = readlane(prop_l, q);
@@ -527,11 +561,14 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     // integer inverse CDF (:627-628): first own block whose running total exceeds x.  Lanes past
                     // k_own hold garbage, but block k_own - 1 always qualifies (its total is m_r[t] > x).
                     const int scan = K32 ? wave_inclusive_scan32(w_piv) : wave_inclusive_scan(w_piv);
-                    const unsigned long long hit = __builtin_amdgcn_ballot_w64((uint32_t)scan > prop) | last_own_bit;
-                    const uint32_t s_loc = (uint32_t)__builtin_ctzll(hit);
+                    const unsigned long long hit = __builtin_amdgcn_ballot_w64((uint32_t)scan > prop);
+                    uint32_t first_hit;  // (s_ff1 gives ~0u for an empty mask: the clamp below is the safety net)
+                    __asm__("s_ff1_i32_b64 %0, %1" : "=s"(first_hit) : "s"(hit));
+                    const uint32_t s_loc = min(first_hit, last_own);
                     FSTAMP_STEP(2);
                     if (s_loc == r_loc) {  // r == s: accepted as is (T > 0 here), nothing changes (:109-112)
-                        book(n_r_r != 1, T);
+                        if (n_r_r != 1 && lane == 0) acc_l0 += 1;
+                        if constexpr (TM) book_min_on(n_r_r != 1, T);
                         return;
                     }
                     const uint32_t r = own_base + r_loc, s = own_base + s_loc;
@@ -600,13 +637,13 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     const unsigned long long b_far = __builtin_amdgcn_ballot_w64(fabs(lhs - est) > c_tol * est);
                     FSTAMP_STEP(7);
                     if ((b_lt | ~b_far) == 0) {  // clearly rejected
-                        book_min(false, T);
+                        if constexpr (TM) book_min_on(false, T);
                         return;
                     }
                     unsigned long long b_acc = b_lt;
                     if (__builtin_expect(b_far == 0, 0)) b_acc = __builtin_amdgcn_ballot_w64(lhs < accu1 * exp(z));
                     if (b_acc == 0 || n_r_r == 1) {  // (:467-471: veto after the draw)
-                        book_min(false, T);
+                        if constexpr (TM) book_min_on(false, T);
                         return;
                     }
                     // ---- apply_mcmc_moves, blockmodel.cc:461-503 ----
@@ -628,9 +665,13 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     }
                     wfence();
                     FSTAMP_STEP(8);
-                    book_min(true, T);
+                    if constexpr (TM) book_min_on(true, T);
                 };
-                for (uint32_t q = 0; q < cnt; ++q) step(q);
+                if (track_min != 0u) {
+                    for (uint32_t q = 0; q < cnt; ++q) step(std::true_type{}, q);
+                } else {
+                    for (uint32_t q = 0; q < cnt; ++q) step(std::false_type{}, q);
+                }
             };
 
             // chunk pipeline: the feeder is one chunk ahead; one workgroup barrier per chunk
