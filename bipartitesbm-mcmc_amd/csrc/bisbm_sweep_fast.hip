@@ -703,7 +703,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     }
     if (!stopped) rate = (double)acc_l0 / (double)p.duration;  // :100
 
-    // chain state -> HBM (wave 0)
+    // chain state -> HBM (stepping wave)
     __syncthreads();
     if (!is_main) return;
     for (uint32_t i = lane; i < ka * kb; i += kWave) m_g[i] = mq[(i / kb) * S + (i % kb)];
@@ -727,6 +727,8 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
         sc->last_rate = rate;
         sc->last_accepted = acc_l0;
         sc->last_sweeps = sweeps_done;
+        // give the SIMD back: workgroups of a later round (more chains than the chip holds at once) claim afresh
+        if (p.simd_claims != nullptr) atomicSub(&p.simd_claims[role[wave_in_wg]], 1u);
     }
 }
 
