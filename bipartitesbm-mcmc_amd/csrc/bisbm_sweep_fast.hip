@@ -17,10 +17,11 @@
 //     per-step selects);
 //   * the pivot neighbour of the proposal depends only on the step's uniform and the row, so its label
 //     is picked up during the same walk.
-// Two waves per chain: wave 0 runs the steps, wave 1 ("feeder") prepares the NEXT chunk meanwhile --
+// Two waves per chain: one runs the steps, the other ("feeder") prepares the NEXT chunk meanwhile --
 // visit order, row extents, own labels, the label walk into a second set of k_v counters, the pivot
 // neighbour's label -- and hands it over through LDS at one workgroup barrier per chunk.  The memory latency of
-// a chunk's preparation (several dependent HBM round trips) is thereby off the step path entirely.
+// a chunk's preparation (several dependent HBM round trips) is thereby off the step path entirely.  Which wave
+// steps is settled at kernel start so that no SIMD of the chip hosts the stepping waves of two chains.
 // State on chip: the a x b quadrant of m (odd row stride: rows and columns conflict-free) and eta in
 // LDS; m_r / n_r in registers (lane i <-> block i of each type).  dS and the Hastings sums are DPP
 // butterflies; the four log_q values are one SIMT evaluation; the four uniforms of a step come from one
