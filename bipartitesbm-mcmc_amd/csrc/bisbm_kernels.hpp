@@ -63,8 +63,9 @@ struct SweepParams {
     int eta_in_lds;
     int vlist_in_lds;
     // production kernel: one counter per SIMD of the chip (kSimdClaims entries, zeroed before the launch) through which
-    // the workgroups keep their stepping waves on different SIMDs; NULL: wave 0 steps
+    // the workgroups keep their stepping waves on different SIMDs; NULL: wave `fixed_stepping_wave` (0 or 1) steps
     uint32_t* simd_claims;
+    uint32_t fixed_stepping_wave;
 };
 constexpr uint32_t kSimdClaims = 1u << 14;  // index: XCC_ID[3:0] | HW_ID se, sh, cu [15:8] | simd [5:4]
 

@@ -608,9 +608,11 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     if (lds > 160 * 1024) return fail(h, BISBM_ERR_UNSUPPORTED, "chain state needs %zu B of LDS (> 160 KiB)", lds);
 
     p.simd_claims = nullptr;
+    p.fixed_stepping_wave = 0;
     if (fast) {
-        const char* fixed = getenv("BISBM_FIXED_ROLES");  // =1: wave 0 always steps (A/B checks)
-        if (!(fixed && fixed[0] == '1')) {
+        const char* fixed = getenv("BISBM_FIXED_ROLES");  // =1: wave 0 always steps, =2: wave 1 (A/B checks, tests)
+        if (fixed && fixed[0] == '2') p.fixed_stepping_wave = 1;
+        if (!(fixed && (fixed[0] == '1' || fixed[0] == '2'))) {
             if (!h->d_simd_claims) HIPCHK(h, dalloc(&h->d_simd_claims, kSimdClaims));
             HIPCHK(h, hipMemsetAsync(h->d_simd_claims, 0, sizeof(uint32_t) * kSimdClaims, h->stream));
             p.simd_claims = h->d_simd_claims;

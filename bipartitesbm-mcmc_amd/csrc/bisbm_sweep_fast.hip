@@ -137,7 +137,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     if (lane == 0) role[wave_in_wg] = ((xcc_id & 0xfu) << 10) | ((hw_id >> 6) & 0x3fcu) | ((hw_id >> 4) & 3u);
     __syncthreads();
     if (wave_in_wg == 0 && lane == 0) {
-        uint32_t pick = 0;
+        uint32_t pick = p.simd_claims != nullptr ? 0u : (p.fixed_stepping_wave & 1u);
         if (p.simd_claims != nullptr && atomicAdd(&p.simd_claims[role[0]], 1u) != 0u) {
             if (atomicAdd(&p.simd_claims[role[1]], 1u) == 0u) {
                 pick = 1;

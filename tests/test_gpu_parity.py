@@ -179,6 +179,32 @@ def test_hot_step_many_chains_philox():
         assert cum[c] == pytest.approx(o.get_entropy(), rel=1e-9)
 
 
+@pytest.mark.parametrize("roles", ["claims", "1", "2"])
+def test_either_wave_can_step(roles, monkeypatch):
+    """The production kernel settles at start which of a workgroup's two waves steps (per-SIMD claims); whichever it is
+    -- wave 0 (BISBM_FIXED_ROLES=1), wave 1 (=2) or the claimed one -- the chains equal the oracle's."""
+    if roles != "claims":
+        monkeypatch.setenv("BISBM_FIXED_ROLES", roles)
+    else:
+        monkeypatch.delenv("BISBM_FIXED_ROLES", raising=False)
+    name, na, nb, ne, ka, kb, eps, hubs, iso = next(c for c in CASES if c[0] == "hubs_isolated")
+    rowptr, col = _random_graph(11, na, nb, ne, ka, kb, hubs, iso)
+    labels = O.contiguous_labels(na, nb, ka, kb)
+    n, chains, first = na + nb, 6, 7
+    g = gpu_model(rowptr, col, na, nb, ka, kb, eps, labels, n_chains=chains, rng="philox", seed=99, first_chain_id=first)
+    g.shuffle_bisbm()
+    mh = B.MetropolisHasting()
+    rates = mh.anneal(g, "constant", [1.0], 5 * n, BIG)
+    rates2 = mh.anneal(g, "exponential", [2.0, 0.999], 5 * n, 3 * n)
+    for c in range(chains):
+        o = O.OracleModel(rowptr, col, na, nb, ka, kb, eps, labels)
+        o.seed_philox(99, first + c)
+        o.shuffle_bisbm()
+        assert o.anneal("constant", [1.0], 5 * n, BIG) == rates[c]
+        assert o.anneal("exponential", [2.0, 0.999], 5 * n, 3 * n) == rates2[c]
+        assert_state_equal(g, o, c)
+
+
 def test_config2_256_chains_philox():
     """BASELINE config 2: n_1000, Ka=4, Kb=6, 256 independent chains, constant T=1."""
     rowptr, col, na, nb = O.load_graph("n_1000")
