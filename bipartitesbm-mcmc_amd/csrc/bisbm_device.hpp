@@ -475,20 +475,92 @@ __device__ __forceinline__ double log_q_closed(double kd, double sq, double r, d
     return ((c.lfc - logn) + t2) + corr;
 }
 
+// exp(-t) for 0 <= t < 700 to ~2e-16 relative: ln 2 in two parts, degree-12 Taylor polynomial on |r| <= ln(2)/2
+__device__ __forceinline__ double exp_neg(double t) {
+    const double kf = rint(t * -0x1.71547652b82fep+0);              // -t log2(e), rounded
+    double r = __builtin_fma(kf, -0x1.62e42fee00000p-1, -t);         // -t - kf ln2_hi (exact)
+    r = __builtin_fma(kf, -0x1.a39ef35793c76p-33, r);               //        - kf ln2_lo
+    double p = 0x1.1eed8eff8d898p-29;                               // 1/12!
+    p = __builtin_fma(p, r, 0x1.ae64567f544e4p-26);                 // 1/11!
+    p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);                 // 1/10!
+    p = __builtin_fma(p, r, 0x1.71de3a556c734p-19);                 // 1/9!
+    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16);                 // 1/8!
+    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);                 // 1/7!
+    p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10);                 // 1/6!
+    p = __builtin_fma(p, r, 0x1.1111111111111p-7);                  // 1/5!
+    p = __builtin_fma(p, r, 0x1.5555555555555p-5);                  // 1/4!
+    p = __builtin_fma(p, r, 0x1.5555555555555p-3);                  // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    int e;
+    __asm__("v_cvt_i32_f64 %0, %1" : "=v"(e) : "v"(kf));
+    return ldexp(p, e);
+}
+
+// log_q_approx for 8 <= u = k / sqrt(n) <= 24 (Philox mode): the reference's formulas (int_part.cc:77-98) with the
+// fixed point v = u sqrt(spence(exp(-v))) of get_v taken to convergence instead of to its |dv| <= 1e-8 stop, and no
+// library calls but one exponential.  With x = exp(-v) <= 3.6e-5 here,
+//   spence(x) = pi^2/6 + v log1p(-x) - Li2(x) = pi^2/6 - sum_k (v/k + 1/k^2) x^k        (three terms: x^4 v/4 < 5e-18),
+//   d spence / dv = v x / (1 - x),
+// so two Newton steps from v0 = (pi/sqrt 6) u land on the root to ~1e-15 (the plain iteration contracts by
+// rho = u^2 x / 2 <= 1.2e-3 per step; Newton squares the 1.2e-3 starting error twice); x follows v through
+// exp(-dv) as a polynomial (|dv| <= 1.3e-3).  At the root v / u = sqrt(spence), so
+//   log v - log u = log(pi/sqrt 6) + log1p(-T / (pi^2/6)) / 2,      T = pi^2/6 - spence,
+// and the two remaining log1p arguments are <= 1.2e-3: five and six series terms.
+// Against the literal evaluation as restated for the tests: <= 5e-16 relative for u >= 13, <= 1.5e-14 for
+// 10 <= u < 13, <= 1.1e-12 for 8 <= u < 10 -- the differences are the literal's stopping tolerance: iterated to
+// |dv| <= 1e-14 it returns this function's value to the last digit.
+__device__ __forceinline__ double log_q_mid(double kd, double sq, double r, double logn, const LogQConsts& c) {
+    const double kC6 = 0x1.a51a6625307d3p+0;  // pi^2 / 6
+    const double kThird = 0x1.5555555555555p-2, kNinth = 0x1.c71c71c71c71cp-4;
+    const double u = kd * r;
+    double v = 0x1.48552f88091a8p+0 * u;  // (pi / sqrt 6) u
+    double x = exp_neg(v);
+    double T, s, rs;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        T = x * ((v + 1.0) + x * (__builtin_fma(0.5, v, 0.25) + x * __builtin_fma(kThird, v, kNinth)));
+        sqrt_rsqrt(kC6 - T, s, rs);
+        const double rho = (0.5 * u) * rs * (v * x) * (1.0 + x);
+        const double d = __builtin_fma(u, s, -v);
+        const double dv = __builtin_fma(d, __builtin_fma(rho, rho, rho), d);  // d / (1 - rho) to O(rho^3)
+        v = v + dv;
+        const double t = -dv;  // x <- x exp(-dv)
+        double e = __builtin_fma(0.2, t, 1.0);
+        e = __builtin_fma(0.25 * t, e, 1.0);
+        e = __builtin_fma(kThird * t, e, 1.0);
+        e = __builtin_fma(0.5 * t, e, 1.0);
+        e = __builtin_fma(t, e, 1.0);
+        x = x * e;
+    }
+    T = x * ((v + 1.0) + x * (__builtin_fma(0.5, v, 0.25) + x * __builtin_fma(kThird, v, kNinth)));
+    sqrt_rsqrt(kC6 - T, s, rs);
+    const double t = T * 0x1.37423899a1558p-1;  // T / (pi^2/6)
+    double l1 = __builtin_fma(0.2, t, 0.25);    // log1p(-t) = -t (1 + t/2 + t^2/3 + t^3/4 + t^4/5)
+    l1 = __builtin_fma(l1, t, kThird);
+    l1 = __builtin_fma(l1, t, 0.5);
+    l1 = __builtin_fma(l1, t, 1.0);
+    l1 = -t * l1;
+    const double y = x * __builtin_fma(0.5 * u, u, 1.0);
+    double l2 = __builtin_fma(0x1.5555555555555p-3, y, 0.2);  // log1p(-y), one term more
+    l2 = __builtin_fma(l2, y, 0.25);
+    l2 = __builtin_fma(l2, y, kThird);
+    l2 = __builtin_fma(l2, y, 0.5);
+    l2 = __builtin_fma(l2, y, 1.0);
+    l2 = -y * l2;
+    const double lf = __builtin_fma(0.5, l1 - l2, c.lfc);                                  // :94-95
+    const double g = __builtin_fma(u * x, __builtin_fma(x, __builtin_fma(kThird, x, 0.5), 1.0), 2.0 * s);  // :96
+    return (lf - logn) + sq * g;                                                           // :97
+}
+
 // log_q_approx, int_part.cc:89-98.
 //
 // Branch test `k < pow(n, 1/4.)` (:90) is evaluated as k^4 < n in integers: for n < 2^32 the
 // correctly rounded pow can equal an integer only when n is a perfect fourth power, and the distance
 // of n^(1/4) to the nearest integer is otherwise >= 1/(4 j^3) >> ulp, so the two tests agree.
 //
-// FAST (Philox mode only), tier u > 21: every x = exp(-v) met by get_v is < 8e-10, where
-//   spence(x) = pi^2/6 - log(x) log1p(-x) - x P(-x)/Q(-x) = pi^2/6 - (v + 1) x + O(v x^2)
-// (log(x) = -v by construction, log1p(-x) = -x, P/Q = 1, all to below 1e-17 relative), hence
-//   u sqrt(spence) = u (pi/sqrt 6)(1 - (3/pi^2)(v + 1) x),
-// and in the closing formula log1p(-y) = -y, log(v/u) = log(pi/sqrt 6) - eps.  The iteration
-// itself (start v = u, stop when |dv| <= 1e-8) is kept, so the iteration count matches the literal
-// code.  Measured against the literal evaluation over u in [21, 60]: <= 4.6e-16 relative (3 ulp),
-// the size of the libm-to-libm differences the literal path has anyway.  Other arguments take the
+// FAST (Philox mode only): u > 24 is log_q_closed, 8 <= u <= 24 is log_q_mid (both above); smaller u take the
 // literal path.
 template <bool FAST>
 __device__ inline double log_q_approx(const Tables& t, unsigned long long n, unsigned long long k, double logn_pre) {
@@ -501,34 +573,19 @@ __device__ inline double log_q_approx(const Tables& t, unsigned long long n, uns
         small = k < 65536ull && (k * k) * (k * k) < n;
     }
     if (__builtin_expect(small, 0)) return lbinom_fast(t, n - 1, k - 1) - lgamma_fast(t, (long long)(k + 1));  // :73-75
-    const double C0 = 0x1.48552f88091a8p+0;    // pi / sqrt(6)
-    const double C1 = 0x1.37423899a1558p-2;    // 3 / pi^2
-    const double LFC = -0x1.ef8383c50bb74p+0;  // log(pi/sqrt 6) - 1.5 log 2 - log pi
     double sq, u;
     if (FAST) {
+        // tiers by u^2 = k^2 / n against 24^2 and 8^2, in exact double arithmetic (k^2 < 2^52): the production kernel's
+        // hot step makes the very same tests (logn_pre = logtab[n], loaded by the caller with the other gathers)
+        const double kd = (double)(uint32_t)k, nd = (double)(uint32_t)n, k2 = kd * kd;
         double r;
-        sqrt_rsqrt((double)(uint32_t)n, sq, r);
-        u = (double)(uint32_t)k * r;
-        if (__builtin_expect(u > 24.0, 1))  // logn_pre = logtab[n], loaded by the caller with the other gathers
-            return log_q_closed((double)(uint32_t)k, sq, r, logn_pre, log_q_consts());
+        sqrt_rsqrt(nd, sq, r);
+        if (__builtin_expect(k2 > 576.0 * nd, 1)) return log_q_closed(kd, sq, r, logn_pre, log_q_consts());
+        if (k2 >= ldexp(nd, 6)) return log_q_mid(kd, sq, r, logn_pre, log_q_consts());
+        u = kd * r;
     } else {
         sq = sqrt((double)n);
         u = (double)k / sq;  // :92
-    }
-    if (FAST && u > 21.0) {
-        double v = u, x, eps, delta;
-        int guard = 0;
-        do {  // get_v, :77-87
-            x = exp(-v);
-            eps = C1 * (v + 1.0) * x;
-            const double n_v = u * (C0 * (1.0 - eps));
-            delta = fabs(n_v - v);
-            v = n_v;
-        } while (delta > 1e-8 && ++guard < 1000);
-        x = x * (1.0 - delta);  // exp(-v) after the last update: |v - v_prev| = delta <= 1e-8
-        const double lf = LFC - eps + 0.5 * x * (1.0 + u * u / 2);  // :94-95
-        const double g = 2 * v / u + u * x;                         // :96
-        return lf - log((double)n) + sq * g;                        // :97
     }
     const double v = get_v(u);
     const double lf = log(v) - log1p(-exp(-v) * (1 + u * u / 2)) / 2 - log(2.) * 3 / 2. - log(u) - log(kPi);

@@ -606,19 +606,29 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                         accu1 = butterfly_sum(a1);
                     }
                     FSTAMP_STEP(4);
-                    // log_q of the four (n, k) pairs, one per lane (mod 4).  Tier u = k / sqrt(n) > 24 above the table
-                    // (k^2 > 576 n, evaluated in doubles: the tiers agree to 6e-16 around the boundary) is the closed
-                    // form of bisbm_device.hpp (log_q_approx<true>) written out on pinned constants; anything else
-                    // goes through log_q<true>.
+                    // log_q of the four (n, k) pairs, one per lane (mod 4).  Above the table, tier u = k / sqrt(n) > 24
+                    // (k^2 > 576 n: blocks of more than ~12 000 nodes at mean degree 20) is the closed form of
+                    // bisbm_device.hpp on pinned constants and tier 8 <= u <= 24 the converged evaluation, the same
+                    // functions and the same exact tier tests as log_q_approx<true>; anything else goes through
+                    // log_q<true> itself.
                     double lq;
                     {
                         const int qk2 = qk < qn ? qk : qn;
                         const double nd = (double)qn, kd = (double)qk2;
-                        const bool direct = qn > kQNmax && kd * kd > c_576 * nd;
+                        const double k2 = kd * kd;
+                        const bool direct = qn > kQNmax && k2 > c_576 * nd;
                         if (__builtin_expect(__builtin_amdgcn_ballot_w64(!direct) == 0, 1)) {  // (lanes repeat mod 4)
                             double sq, rr;
                             sqrt_rsqrt(nd, sq, rr);
                             lq = log_q_closed(kd, sq, rr, logn, lqc);
+                        } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= ldexp(nd, 6))) == 0) {
+                            // blocks of a few thousand nodes (8 <= u <= 24 for some of the four arguments): the
+                            // converged tier, and the closed form where it applies -- both straight-line code
+                            double sq, rr;
+                            sqrt_rsqrt(nd, sq, rr);
+                            const double lq_mid = log_q_mid(kd, sq, rr, logn, lqc);
+                            const double lq_far = log_q_closed(kd, sq, rr, logn, lqc);
+                            lq = direct ? lq_far : lq_mid;
                         } else {
                             lq = log_q<true>(tab, qn, qk, logn);
                         }

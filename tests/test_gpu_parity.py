@@ -3,6 +3,7 @@
   * the oracle restatement on the same seeded inputs (both RNG modes, integers bit-exact),
   * size-independent properties at BASELINE.json's full size."""
 import importlib
+import math
 import os
 
 import numpy as np
@@ -117,6 +118,8 @@ CASES = [
     ("direct_tier_wide", 72000, 72000, 216000, 40, 33, 1.0, 0, 0),
     # ... and k / sqrt(n) around 23: the hot step falls back to the iterated / literal log_q tiers
     ("mid_tier", 5300, 5300, 26500, 2, 2, 1.0, 0, 0),
+    # ... k / sqrt(n) around 10 (blocks of ~1200 nodes): the converged log_q tier in the hot step
+    ("mid_tier_low", 2400, 2400, 28800, 2, 2, 1.0, 0, 0),
     # no edges at all: every node has degree 0 (uniform proposals over all K blocks, blockmodel.cc:616-617)
     ("edgeless", 10, 8, 0, 2, 2, 1.0, 0, 0),
 ]
@@ -384,12 +387,37 @@ def test_device_log_q_matches_oracle():
     table = n < 10001
     assert (got[table] == want[table]).all()  # host-built table: same bits
     assert np.allclose(got[~table], want[~table], rtol=1e-12, atol=0)  # device libm vs glibc
-    # Philox-mode evaluation (closed form of get_v/spence for k/sqrt(n) > 21): a few ulp of the literal one
+    # Philox-mode evaluation: closed form for u = k/sqrt(n) > 24, get_v taken to convergence for 8 <= u <= 24, the
+    # literal code below.  A few ulp of the literal evaluation, except where the literal's own |dv| <= 1e-8 stop shows:
+    # <= 1.5e-14 for 10 <= u < 13, <= 1.1e-12 for 8 <= u < 10 (bisbm_device.hpp, log_q_mid)
+    n_mid = rng.integers(10001, 20_000_000, 4000)
+    k_mid = np.maximum(1, np.round(rng.uniform(8.0, 26.0, 4000) * np.sqrt(n_mid))).astype(np.int64)
+    n = np.concatenate([n, n_mid]).astype(np.int32)
+    k = np.concatenate([k, k_mid]).astype(np.int32)
+    want = np.array([L.orc_log_q(int(a), int(b)) for a, b in zip(n, k)])
+    table = n < 10001
     fast = g.debug_log_q(n, k, fast=True)
     assert (fast[table] == want[table]).all()
-    assert np.allclose(fast[~table], want[~table], rtol=2e-15, atol=0)
-    u = k[~table] / np.sqrt(n[~table].astype(np.float64))
-    assert (u > 21).sum() > 300 and (u <= 21).sum() > 300  # both regimes are exercised
+    nt, kt = n[~table].astype(np.float64), np.minimum(k[~table], n[~table]).astype(np.float64)
+    u2 = kt * kt / nt
+    rel = np.abs(fast[~table] - want[~table]) / np.abs(want[~table])
+    tol = np.where(u2 >= 169, 2e-15, np.where(u2 >= 100, 3e-14, np.where(u2 >= 64, 2e-12, 2e-15)))
+    assert (rel <= tol).all(), (rel / tol).max()
+    assert (u2 > 576).sum() > 300 and ((u2 >= 64) & (u2 <= 576)).sum() > 3000 and (u2 < 64).sum() > 200
+
+    # ... and with get_v iterated to |dv| <= 1e-14 the literal formulas give the converged tier's value to the ulp
+    def literal_converged(nn, kk):
+        sq = math.sqrt(nn)
+        uu = kk / sq
+        v, delta = uu, 1.0
+        while delta > 1e-14:
+            nv = uu * math.sqrt(L.orc_spence(math.exp(-v)))
+            delta, v = abs(nv - v), nv
+        lf = math.log(v) - math.log1p(-math.exp(-v) * (1 + uu * uu / 2)) / 2 - math.log(2.) * 3 / 2. - math.log(uu) - math.log(math.pi)
+        return lf - math.log(nn) + sq * (2 * v / uu - uu * math.log1p(-math.exp(-v)))
+    sel = np.flatnonzero((~table) & (k.astype(np.float64) ** 2 >= 64.0 * n) & (k.astype(np.float64) ** 2 <= 169.0 * n))[:400]
+    conv = np.array([literal_converged(int(n[i]), int(k[i])) for i in sel])
+    assert len(sel) == 400 and np.allclose(fast[sel], conv, rtol=2e-15, atol=0)
 
 
 def test_error_paths():
