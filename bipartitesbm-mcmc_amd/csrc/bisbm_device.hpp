@@ -554,14 +554,75 @@ __device__ __forceinline__ double log_q_mid(double kd, double sq, double r, doub
     return (lf - logn) + sq * g;                                                           // :97
 }
 
+// log1p(-a) for 0 <= a <= 0.25 as -2 atanh(a / (2 - a)): nine odd powers of z <= 0.143 (z^19 / 19 < 1e-17)
+__device__ __forceinline__ double log1p_neg(double a) {
+    const double z = a / (2.0 - a), z2 = z * z;
+    double p = 1.0 / 17.0;
+    p = __builtin_fma(p, z2, 1.0 / 15.0);
+    p = __builtin_fma(p, z2, 1.0 / 13.0);
+    p = __builtin_fma(p, z2, 1.0 / 11.0);
+    p = __builtin_fma(p, z2, 1.0 / 9.0);
+    p = __builtin_fma(p, z2, 1.0 / 7.0);
+    p = __builtin_fma(p, z2, 0.2);
+    p = __builtin_fma(p, z2, 0x1.5555555555555p-2);
+    p = __builtin_fma(p, z2, 1.0);
+    return -2.0 * z * p;
+}
+
+// log_q_approx for 2.5 <= u < 8 (Philox mode): dense graphs, where a block of n_r nodes has u = sqrt(n_r / mean
+// degree).  Same scheme as log_q_mid -- the root of v = u sqrt(spence(exp(-v))) by Newton steps on the series of
+// spence, then the reference's closing formulas -- with everything sized for x = exp(-v) <= 0.041: twelve series
+// terms, four Newton steps, the exponential evaluated afresh for every step, log1p through atanh series.  Straight-line
+// code (~400 instructions) instead of the literal loop over exp / spence / log (~1700 for u = 5).  It returns what the
+// literal formulas return when get_v iterates to |dv| <= 1e-14 (<= 7e-16 relative); the reference's |dv| <= 1e-8 stop
+// leaves up to 4e-10 relative in log_q at u = 2.5 (8e-11 at u = 5, 1e-11 at u = 7).
+__device__ inline double log_q_low(double kd, double sq, double r, double logn, const LogQConsts& c) {
+    const double kC6 = 0x1.a51a6625307d3p+0;  // pi^2 / 6
+    const double u = kd * r;
+    double v = 0x1.48552f88091a8p+0 * u;  // (pi / sqrt 6) u
+    double x, T, s, rs;
+    auto series = [&]() {  // T = pi^2/6 - spence(x) = sum_k (v/k + 1/k^2) x^k
+        double p = __builtin_fma(1.0 / 12.0, v, 1.0 / 144.0);
+        p = __builtin_fma(p, x, __builtin_fma(1.0 / 11.0, v, 1.0 / 121.0));
+        p = __builtin_fma(p, x, __builtin_fma(0.1, v, 0.01));
+        p = __builtin_fma(p, x, __builtin_fma(1.0 / 9.0, v, 1.0 / 81.0));
+        p = __builtin_fma(p, x, __builtin_fma(0.125, v, 1.0 / 64.0));
+        p = __builtin_fma(p, x, __builtin_fma(1.0 / 7.0, v, 1.0 / 49.0));
+        p = __builtin_fma(p, x, __builtin_fma(1.0 / 6.0, v, 1.0 / 36.0));
+        p = __builtin_fma(p, x, __builtin_fma(0.2, v, 0.04));
+        p = __builtin_fma(p, x, __builtin_fma(0.25, v, 0.0625));
+        p = __builtin_fma(p, x, __builtin_fma(0x1.5555555555555p-2, v, 1.0 / 9.0));
+        p = __builtin_fma(p, x, __builtin_fma(0.5, v, 0.25));
+        p = __builtin_fma(p, x, v + 1.0);
+        T = p * x;
+    };
+    for (int it = 0; it < 4; ++it) {
+        x = exp_neg(v);
+        series();
+        sqrt_rsqrt(kC6 - T, s, rs);
+        const double rho = (0.5 * u) * rs * (v * x) * __builtin_fma(x, __builtin_fma(x, x + 1.0, 1.0), 1.0);  // u spence' / (2 sqrt spence)
+        const double d = __builtin_fma(u, s, -v);
+        const double w = __builtin_fma(__builtin_fma(rho, rho, rho), rho, rho);  // rho + rho^2 + rho^3
+        v = __builtin_fma(d, w, v + d);
+    }
+    x = exp_neg(v);
+    series();
+    sqrt_rsqrt(kC6 - T, s, rs);
+    const double l1 = log1p_neg(T * 0x1.37423899a1558p-1);           // log(spence / (pi^2/6)) = 2 (log v - log u - log(pi/sqrt 6))
+    const double l2 = log1p_neg(x * __builtin_fma(0.5 * u, u, 1.0));
+    const double lf = __builtin_fma(0.5, l1 - l2, c.lfc);            // :94-95
+    const double g = __builtin_fma(-u, log1p_neg(x), 2.0 * s);      // :96
+    return (lf - logn) + sq * g;                                     // :97
+}
+
 // log_q_approx, int_part.cc:89-98.
 //
 // Branch test `k < pow(n, 1/4.)` (:90) is evaluated as k^4 < n in integers: for n < 2^32 the
 // correctly rounded pow can equal an integer only when n is a perfect fourth power, and the distance
 // of n^(1/4) to the nearest integer is otherwise >= 1/(4 j^3) >> ulp, so the two tests agree.
 //
-// FAST (Philox mode only): u > 24 is log_q_closed, 8 <= u <= 24 is log_q_mid (both above); smaller u take the
-// literal path.
+// FAST (Philox mode only): u > 24 is log_q_closed, 8 <= u <= 24 log_q_mid, 2.5 <= u < 8 log_q_low (all above); smaller
+// u take the literal path.
 template <bool FAST>
 __device__ inline double log_q_approx(const Tables& t, unsigned long long n, unsigned long long k, double logn_pre) {
     const double kPi = 3.14159265358979323846;
@@ -575,13 +636,14 @@ __device__ inline double log_q_approx(const Tables& t, unsigned long long n, uns
     if (__builtin_expect(small, 0)) return lbinom_fast(t, n - 1, k - 1) - lgamma_fast(t, (long long)(k + 1));  // :73-75
     double sq, u;
     if (FAST) {
-        // tiers by u^2 = k^2 / n against 24^2 and 8^2, in exact double arithmetic (k^2 < 2^52): the production kernel's
+        // tiers by u^2 = k^2 / n against 24^2, 8^2 and 2.5^2, in exact double arithmetic (k^2 < 2^52): the production kernel's
         // hot step makes the very same tests (logn_pre = logtab[n], loaded by the caller with the other gathers)
         const double kd = (double)(uint32_t)k, nd = (double)(uint32_t)n, k2 = kd * kd;
         double r;
         sqrt_rsqrt(nd, sq, r);
         if (__builtin_expect(k2 > 576.0 * nd, 1)) return log_q_closed(kd, sq, r, logn_pre, log_q_consts());
         if (k2 >= ldexp(nd, 6)) return log_q_mid(kd, sq, r, logn_pre, log_q_consts());
+        if (4.0 * k2 >= 25.0 * nd) return log_q_low(kd, sq, r, logn_pre, log_q_consts());  // u >= 2.5
         u = kd * r;
     } else {
         sq = sqrt((double)n);

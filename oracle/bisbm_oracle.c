@@ -183,6 +183,24 @@ double orc_log_q_approx(size_t n, size_t k) {
     return lf - log((double)n) + sqrt((double)n) * g;
 }
 
+/* Philox mode (production definition): the same formulas with get_v iterated to convergence
+ * (|dv| <= 1e-14 instead of the reference's 1e-8) for k^2 >= 6.25 n, i.e. u >= 2.5 -- the range the HIP kernels
+ * evaluate by Newton steps on the series of spence (bisbm_device.hpp: log_q_closed / log_q_mid / log_q_low). */
+double orc_log_q_approx_philox(size_t n, size_t k) {
+    if ((double)k < pow((double)n, 1 / 4.)) return orc_log_q_approx(n, k);
+    if (4.0 * ((double)k * (double)k) < 25.0 * (double)n) return orc_log_q_approx(n, k);
+    double u = (double)k / sqrt((double)n);
+    double v = u, delta = 1;
+    for (int guard = 0; delta > 1e-14 && guard < 1000; ++guard) {
+        double n_v = u * sqrt(orc_spence(exp(-v)));
+        delta = fabs(n_v - v);
+        v = n_v;
+    }
+    double lf = log(v) - log1p(-exp(-v) * (1 + u * u / 2)) / 2 - log(2) * 3 / 2. - log(u) - log(M_PI);
+    double g = 2 * v / u - u * log1p(-exp(-v));
+    return lf - log((double)n) + sqrt((double)n) * g;
+}
+
 double orc_q_cache_at(size_t n, size_t k) {
     if (n > ORC_Q_NMAX || k > g_q_kcap) return NAN;
     return g_q[n * (g_q_kcap + 1) + k];
@@ -197,6 +215,13 @@ double orc_log_q(int n, int k) {
         return g_q[(size_t)n * (g_q_kcap + 1) + (size_t)k];
     }
     return orc_log_q_approx((size_t)n, (size_t)k);
+}
+
+double orc_log_q_philox(int n, int k) {
+    if (n <= 0 || k < 1) return 0;
+    if (k > n) k = n;
+    if (n < ORC_Q_NMAX + 1) return orc_log_q(n, k);
+    return orc_log_q_approx_philox((size_t)n, (size_t)k);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -914,10 +939,10 @@ static double transition_ratio(orc_model *m, size_t v, size_t r, size_t s) {
         d[5] = d[5] + orc_lgamma_fast((size_t)(eta_s + 1));
         d[6] = d[6] + -orc_lgamma_fast((size_t)(eta_r - 1 + 1));
         d[7] = d[7] + -orc_lgamma_fast((size_t)(eta_s + 1 + 1));
-        d[0] = d[0] + -orc_log_q(m0r, n_r_r);
-        d[1] = d[1] + -orc_log_q(m0s, n_r_s);
-        d[2] = d[2] + orc_log_q(m1r, n_r_r - 1);
-        d[3] = d[3] + orc_log_q(m1s, n_r_s + 1);
+        d[0] = d[0] + -orc_log_q_philox(m0r, n_r_r);
+        d[1] = d[1] + -orc_log_q_philox(m0s, n_r_s);
+        d[2] = d[2] + orc_log_q_philox(m1r, n_r_r - 1);
+        d[3] = d[3] + orc_log_q_philox(m1s, n_r_s + 1);
         m->phx_accu0 = deg == 0 ? 1. : butterfly64(a0);
         m->phx_accu1 = deg == 0 ? 1. : butterfly64(a1);
         m->accu_r = m->phx_accu1 / m->phx_accu0;

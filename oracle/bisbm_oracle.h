@@ -55,6 +55,8 @@ void orc_init_tables(size_t lgamma_size, size_t q_kcap); /* grows the process-wi
 double orc_lgamma_fast(size_t x);
 double orc_safelog_fast(size_t x);
 double orc_log_q(int n, int k);
+double orc_log_q_philox(int n, int k); /* Philox-mode definition: get_v to convergence for u >= 2.5 */
+double orc_log_q_approx_philox(size_t n, size_t k);
 double orc_log_q_approx(size_t n, size_t k);
 double orc_q_cache_at(size_t n, size_t k); /* raw table cell, k <= kcap */
 double orc_spence(double x);

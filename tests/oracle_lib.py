@@ -55,6 +55,8 @@ def lib():
     L.orc_log_q.argtypes = [C.c_int, C.c_int]
     L.orc_log_q_approx.restype = C.c_double
     L.orc_log_q_approx.argtypes = [C.c_size_t, C.c_size_t]
+    L.orc_log_q_philox.restype = C.c_double
+    L.orc_log_q_philox.argtypes = [C.c_int, C.c_int]
     L.orc_q_cache_at.restype = C.c_double
     L.orc_q_cache_at.argtypes = [C.c_size_t, C.c_size_t]
     L.orc_spence.restype = C.c_double

@@ -449,3 +449,23 @@ def test_geospace_known_values():
     assert a[0] == 500 and a[-1] == 4 and b[0] == 500 and b[-1] == 6 and len(a) == len(b)
     assert all(x >= y for x, y in zip(a, a[1:])) and all(x >= y for x, y in zip(b, b[1:]))
     assert O.geospace(5, 2, 9, 3, 1.0) == ([0], [0])  # ratio <= 1
+
+
+def test_philox_mode_log_q_definition():
+    """Philox mode iterates get_v to convergence for u = k/sqrt(n) >= 2.5 (what the HIP kernels evaluate in closed form):
+    identical to the reference's evaluation elsewhere, and inside that range different only by what the reference's
+    |dv| <= 1e-8 stop leaves (<= 4e-10 relative at u = 2.5, shrinking fast with u)."""
+    L = O.lib()
+    rng = np.random.default_rng(5)
+    for n, k in [(5000, 40), (10000, 500), (20000, 5), (160000, 21), (10001, 150), (1000000, 2400)]:  # table, small k, u < 2.5
+        assert L.orc_log_q_philox(n, k) == L.orc_log_q(n, k)
+    worst = {}
+    for _ in range(3000):
+        n = int(rng.integers(10001, 30_000_000))
+        u = float(rng.uniform(2.5, 40.0))
+        k = int(round(u * np.sqrt(n)))
+        a, b = L.orc_log_q_philox(n, k), L.orc_log_q(n, k)
+        band = 2.5 if u < 4 else 4 if u < 6 else 6 if u < 8 else 8 if u < 10 else 10 if u < 13 else 13
+        worst[band] = max(worst.get(band, 0.0), abs(a - b) / abs(b))
+    assert worst[2.5] < 8e-10 and worst[4] < 2e-10 and worst[6] < 2e-11 and worst[8] < 2e-12 and worst[10] < 3e-14 and worst[13] < 2e-15
+    assert worst[2.5] > 1e-11  # (the stop does leave something there: the two definitions are not the same function)
