@@ -29,7 +29,7 @@
 //
 // A lone wave per SIMD pays one issue slot (~4.3 cycles) for EVERY instruction and 25-40 cycles for every
 // vector->scalar->vector crossing (tools/probe/issue_latency.hip), so the step exists twice:
-//   * the hot step: 1 <= deg <= 64, target drawn from column m[.][t], T > 0, closed-form log_q tier.
+//   * the hot step: 1 <= deg <= 255, target drawn from column m[.][t], T > 0, closed-form log_q tier.
 //     Straight-line code, one test for "rare" at the top, r == s leaves right after the proposal, one tier
 //     test, one crossing for the accept decision; lane patterns are bit arithmetic on per-lane constant
 //     masks, the constants of the closed forms sit in vector registers (the scalar file is full);
@@ -89,6 +89,7 @@ struct __attribute__((packed, aligned(4))) Id4 {  // four consecutive column ids
 
 constexpr uint32_t kHistStride = 68;  // bytes per k_v row: 64 counters + pad (17 dwords: odd, conflict-free)
 constexpr uint32_t kHandWords = 5;    // v, row begin, degree, own label, pivot label
+constexpr uint32_t kRowCap = 255;     // longest row the feeder walks (a k_v counter is a byte); longer rows: per-step side path
 
 // a double constant held in a vector register pair for the whole kernel (64-bit literals are not encodable
 // and the scalar file is full: without this the hot loop rebuilds them with s_mov pairs at every use)
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t ka = p.ka, kb = p.kb, K = ka + kb, na = p.na, nb = p.nb;
     const uint32_t D = p.maxdeg + 1, S = kb | 1u;
-    const uint32_t row_cap = p.maxdeg < (uint32_t)kWave ? p.maxdeg : (uint32_t)kWave;  // neighbours walked per row by the feeder
+    const uint32_t row_cap = p.maxdeg < kRowCap ? p.maxdeg : kRowCap;  // neighbours walked per row by the feeder
     // LDS layout, dword offsets
     const uint32_t o_mq = 0, o_eta = ka * S;
     const uint32_t o_hist8 = o_eta + (EL ? K * D : 0u);                      // two buffers of k_v rows
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                 // slots load node 0 and add zero.
                 for (uint32_t w = 0; w < kHistStride / 4; ++w) hist8w[lane * (kHistStride / 4) + w] = 0;
                 wfence();
-                const bool mine = lane < cnt && deg_l <= (uint32_t)kWave;  // longer rows: per-step side path
+                const bool mine = lane < cnt && deg_l <= kRowCap;  // longer rows: per-step side path
 #if defined(BISBM_ABLATE) && (BISBM_ABLATE & 64)
                 const uint32_t my_deg = 0u;  // diagnostic build: the feeder walks nothing, every k_v is zero (wrong results)
 #else
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                 const uint32_t tloc_l = ((uint32_t)piv_l - oth_base) & 63u;
                 const uint32_t rloc_l = r_l - own_base;
                 uint32_t prop_l = draw_target(__builtin_amdgcn_ds_bpermute((int)(tloc_l << 2), mr_oth), ud_R, ud_tgt);
-                if (k_own == 1u || deg_l == 0u || deg_l > (uint32_t)kWave || (CT && T_const == 0.) || never_direct)
+                if (k_own == 1u || deg_l == 0u || deg_l > kRowCap || (CT && T_const == 0.) || never_direct)
                     prop_l |= 0x80000000u;
 
                 // anneal()'s bookkeeping after a step, metropolis_hasting.cc:85-94
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     const int32_t m_rt = lane < k_oth ? m_rt_raw : 0;
                     const int eta_r = (int)eta_rd(r * D + deg);
                     uint32_t t_piv = (uint32_t)readlane(piv_l, q);
-                    if (deg > (uint32_t)kWave) {  // rows longer than a wave: straight from HBM
+                    if (deg > kRowCap) {  // rows the feeder does not walk: straight from HBM
                         const uint32_t beg = readlane(beg_l, q);
                         slow_hist[lane] = 0;
                         wfence();
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     book(ok, T);
                 };
 
-                // ---- the 64 steps.  Hot path: 1 <= deg <= 64, target drawn from column m[.][t], T > 0 ----
+                // ---- the 64 steps.  Hot path: 1 <= deg <= 255, target drawn from column m[.][t], T > 0 ----
                 const uint32_t last_own = k_own - 1;
                 const double invT_const = 1.0 / T_const;
                 // One step.  Early returns only (each is a jump to the loop latch); the rare cases leave through

@@ -96,10 +96,11 @@ def test_golden_rng_free_state(golden):
 def _random_graph(seed, na, nb, ne, ka, kb, hubs=0, isolated=0):
     a, b = SYN.planted_edges(na - isolated, nb - isolated, ne, max(ka, 1), max(kb, 1), seed=seed)
     b = b - (na - isolated) + na  # keep b ids in [na, na+nb-isolated)
-    if hubs:  # a few nodes with degree > 64 (more than one wave of neighbours)
+    if hubs:  # a few nodes with degree ~150 (several rounds of the feeder's walk); hubs == 1: one node with degree > 255
         rng = np.random.default_rng(seed + 100)
-        ha = rng.integers(0, hubs, 150 * hubs).astype(np.uint64)
-        hb = (na + rng.integers(0, nb - isolated, 150 * hubs)).astype(np.uint64)
+        n_hub_edges = 150 * hubs if hubs > 1 else 600
+        ha = rng.integers(0, hubs, n_hub_edges).astype(np.uint64)
+        hb = (na + rng.integers(0, nb - isolated, n_hub_edges)).astype(np.uint64)
         a, b = np.concatenate([a, ha]), np.concatenate([b, hb])
     rowptr, col = O.edge_to_csr(a, b, na + nb)
     return rowptr, col
@@ -110,6 +111,7 @@ CASES = [
     ("tiny", 12, 9, 40, 3, 2, 0.5, 0, 0),
     ("ka1", 40, 30, 300, 1, 4, 1.0, 0, 0),
     ("hubs_isolated", 300, 200, 3000, 5, 7, 1.0, 3, 4),
+    ("huge_hub", 300, 200, 3000, 5, 7, 1.0, 1, 0),    # degree > 255: beyond the byte counters of the feeder's walk
     ("wideK", 400, 300, 6000, 70, 3, 2.0, 0, 0),       # K_type > 64: chunked lane loops
     ("big_m_r", 150, 150, 60000, 2, 3, 1.0, 0, 0),     # m_r > 10^4: log_q_approx on the device
     # production kernel's hot step: m_r > 10^4 and k / sqrt(n) > 24 (closed-form log_q tier), K <= 32 ...
