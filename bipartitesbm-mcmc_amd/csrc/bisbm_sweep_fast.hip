@@ -29,7 +29,7 @@
 //
 // A lone wave per SIMD pays one issue slot (~4.3 cycles) for EVERY instruction and 25-40 cycles for every
 // vector->scalar->vector crossing (tools/probe/issue_latency.hip), so the step exists twice:
-//   * the hot step: 1 <= deg <= 255, target drawn from column m[.][t], T > 0, closed-form log_q tier.
+//   * the hot step: 1 <= deg <= 255, target drawn from column m[.][t], closed-form log_q tier.
 //     Straight-line code, one test for "rare" at the top, r == s leaves right after the proposal, one tier
 //     test, one crossing for the accept decision; lane patterns are bit arithmetic on per-lane constant
 //     masks, the constants of the closed forms sit in vector registers (the scalar file is full);
@@ -347,6 +347,9 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     which_l = (uint32_t)(ud_idx * (double)deg_l);
                     if (which_l >= deg_l) which_l = deg_l ? deg_l - 1 : 0;
                 }
+                // the temperatures of the 64 steps (:84), lane = step: one table read or one pow / log per lane per chunk
+                double T_l = T_const;
+                if (!CT) T_l = temperature_of(p, sweep_step0 + node_base + vi0 + lane);
                 // The proposal's random part (blockmodel.cc:619-628) for all 64 steps at once, lane = step: the
                 // opposite type's labels and m_r are frozen during the phase, so the R test (:622-624) and the
                 // inverse-CDF target x do not depend on the moves made inside the chunk.  Bit 31 set: uniform
@@ -534,10 +537,10 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                 // steps of a T >= 1 run carry no test of it)
                 auto step = [&](auto tm, uint32_t q) {
                     constexpr bool TM = decltype(tm)::value;
-                    const double T = CT ? T_const : temperature_of(p, sweep_step0 + node_base + vi0 + q);  // :84
+                    const double T = CT ? T_const : readlane(T_l, q);  // :84
                     FSTAMP_STEP(0);
                     const uint32_t prop = readlane(prop_l, q);
-                    if (__builtin_expect((int32_t)prop < 0 || (!CT && T == 0.), 0)) {
+                    if (__builtin_expect((int32_t)prop < 0, 0)) {
                         step_general(q, T);
                         return;
                     }
@@ -568,9 +571,10 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     __asm__("s_ff1_i32_b64 %0, %1" : "=s"(first_hit) : "s"(hit));
                     const uint32_t s_loc = min(first_hit, last_own);
                     FSTAMP_STEP(2);
-                    if (s_loc == r_loc) {  // r == s: accepted as is (T > 0 here), nothing changes (:109-112)
-                        if (n_r_r != 1 && lane == 0) acc_l0 += 1;
-                        if constexpr (TM) book_min_on(n_r_r != 1, T);
+                    if (s_loc == r_loc) {  // r == s: dS = 0, accepted as is unless T == 0; nothing changes (:109-112, :49-50)
+                        const bool ok = n_r_r != 1 && (CT || T != 0.);
+                        if (ok && lane == 0) acc_l0 += 1;
+                        if constexpr (TM) book_min_on(ok, T);
                         return;
                     }
                     const uint32_t r = own_base + r_loc, s = own_base + s_loc;
@@ -640,23 +644,30 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     d = d + lq * sign_q;
                     const double dS = K32 ? butterfly_sum_low32(d) : butterfly_sum(d);
                     FSTAMP_STEP(6);
-                    // accept (:47-61): u accu0 < accu1 exp(-dS/T), decided on a 1e-7-accurate exponential unless
-                    // the two sides are within 1e-5 of each other (then the exact one decides)
-                    const double z = -dS * (CT ? invT_const : 1.0 / T);
-                    const double est = accu1 * exp2_filter(z * c_l2e);
-                    const double lhs = readlane(ud_acc, q) * accu0;
-                    const unsigned long long b_lt = __builtin_amdgcn_ballot_w64(lhs < est);
-                    const unsigned long long b_far = __builtin_amdgcn_ballot_w64(fabs(lhs - est) > c_tol * est);
-                    FSTAMP_STEP(7);
-                    if ((b_lt | ~b_far) == 0) {  // clearly rejected
-                        if constexpr (TM) book_min_on(false, T);
-                        return;
-                    }
-                    unsigned long long b_acc = b_lt;
-                    if (__builtin_expect(b_far == 0, 0)) b_acc = __builtin_amdgcn_ballot_w64(lhs < accu1 * exp(z));
-                    if (b_acc == 0 || n_r_r == 1) {  // (:467-471: veto after the draw)
-                        if constexpr (TM) book_min_on(false, T);
-                        return;
+                    if (!CT && T == 0.) {  // the greedy tail of a cooling schedule (:49-50): dS < 0 decides
+                        if (!(dS < 0.) || n_r_r == 1) {
+                            if constexpr (TM) book_min_on(false, T);
+                            return;
+                        }
+                    } else {
+                        // accept (:47-61): u accu0 < accu1 exp(-dS/T), decided on a 1e-7-accurate exponential unless
+                        // the two sides are within 1e-5 of each other (then the exact one decides)
+                        const double z = -dS * (CT ? invT_const : 1.0 / T);
+                        const double est = accu1 * exp2_filter(z * c_l2e);
+                        const double lhs = readlane(ud_acc, q) * accu0;
+                        const unsigned long long b_lt = __builtin_amdgcn_ballot_w64(lhs < est);
+                        const unsigned long long b_far = __builtin_amdgcn_ballot_w64(fabs(lhs - est) > c_tol * est);
+                        FSTAMP_STEP(7);
+                        if ((b_lt | ~b_far) == 0) {  // clearly rejected
+                            if constexpr (TM) book_min_on(false, T);
+                            return;
+                        }
+                        unsigned long long b_acc = b_lt;
+                        if (__builtin_expect(b_far == 0, 0)) b_acc = __builtin_amdgcn_ballot_w64(lhs < accu1 * exp(z));
+                        if (b_acc == 0 || n_r_r == 1) {  // (:467-471: veto after the draw)
+                            if constexpr (TM) book_min_on(false, T);
+                            return;
+                        }
                     }
                     // ---- apply_mcmc_moves, blockmodel.cc:461-503 ----
                     const uint32_t v = readlane(v_l, q);
