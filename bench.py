@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--ka", type=int, default=32)
     ap.add_argument("--kb", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shuffle-ids", action="store_true",
+                    help="custom workload: renumber the nodes of each type at random (ids that carry no structure)")
     args = ap.parse_args()
 
     import torch
@@ -106,6 +108,11 @@ def main():
     na, nb, ka, kb, E = args.na, args.nb, args.ka, args.kb, args.edges
     n = na + nb
     a, b = syn.planted_edges(na, nb, E, ka, kb, seed=1)
+    if args.shuffle_ids:
+        import numpy as np
+        rs = np.random.default_rng(7)
+        pa, pb = rs.permutation(na).astype(a.dtype), rs.permutation(nb).astype(b.dtype)
+        a, b = pa[a], pb[b - na] + na
     rowptr, col = pkg.edge_to_adj((a, b), n)
     del a, b
     labels = syn.contiguous_labels(na, nb, ka, kb)
@@ -179,7 +186,7 @@ def main():
         avg_kernel_s = kernel_ms / max(args.steps, 1) / 1e3
         balg = b_alg_per_update(n, E)
         achieved = balg * per_launch_updates / avg_kernel_s / 1e9
-        default_cfg = (na, nb, E, ka, kb, args.chains) == (500_000, 500_000, 10_000_000, 32, 32, 1024)
+        default_cfg = (na, nb, E, ka, kb, args.chains) == (500_000, 500_000, 10_000_000, 32, 32, 1024) and not args.shuffle_ids
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
         # WRITE_SIZE, separate runs of this same command); only quoted for the workload they were measured on
         traffic, traffic_src = None, None
@@ -206,7 +213,8 @@ def main():
             "config": {
                 "workload": ("BASELINE configs[2]: " if default_cfg else "custom: ")
                 + "planted bipartite N_a=%d N_b=%d E=%d Ka=%d Kb=%d, %d chains/GPU, constant T=1, eps=1, "
-                  "randomised start, Philox mode" % (na, nb, E, ka, kb, args.chains),
+                  "randomised start, Philox mode%s" % (na, nb, E, ka, kb, args.chains,
+                                                       ", node ids renumbered at random" if args.shuffle_ids else ""),
                 "chains_total": args.chains * world, "step": "one sweep (n node updates) of every chain",
                 "spinup_sweeps_before_warmup": len(spin_ms),
                 "parallelism": "chains sharded, no collective in the sweep path",
