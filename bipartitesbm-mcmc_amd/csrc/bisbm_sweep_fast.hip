@@ -350,6 +350,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                 // the temperatures of the 64 steps (:84), lane = step: one table read or one pow / log per lane per chunk
                 double T_l = T_const;
                 if (!CT) T_l = temperature_of(p, sweep_step0 + node_base + vi0 + lane);
+                const double invT_l = 1.0 / T_l;  // (T == 0: not used, the step is decided by the sign of dS)
                 // The proposal's random part (blockmodel.cc:619-628) for all 64 steps at once, lane = step: the
                 // opposite type's labels and m_r are frozen during the phase, so the R test (:622-624) and the
                 // inverse-CDF target x do not depend on the moves made inside the chunk.  Bit 31 set: uniform
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     } else {
                         // accept (:47-61): u accu0 < accu1 exp(-dS/T), decided on a 1e-7-accurate exponential unless
                         // the two sides are within 1e-5 of each other (then the exact one decides)
-                        const double z = -dS * (CT ? invT_const : 1.0 / T);
+                        const double z = -dS * (CT ? invT_const : readlane(invT_l, q));
                         const double est = accu1 * exp2_filter(z * c_l2e);
                         const double lhs = readlane(ud_acc, q) * accu0;
                         const unsigned long long b_lt = __builtin_amdgcn_ballot_w64(lhs < est);
