@@ -119,11 +119,9 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     uint32_t* const hand_base = lds32 + o_hand;             // per-chunk lane data handed from the feeder wave
     int32_t* const slow_hist = (int32_t*)(lds32 + o_slow);  // 64 counters for rows longer than 64
     uint32_t* const stop_flag = lds32 + o_flag;
-    // anneal()'s early-stop numbers live in LDS, not in registers: most runs do not touch them at all, and as
-    // loop-carried scalar registers they cost a set of copies on every path of the step loop
-    const uint32_t o_books = (o_flag + 4u + 1u) & ~1u;
-    double* const bk_emin = (double*)(lds32 + o_books + 2);       // entropy_min_ (metropolis_hasting.cc:75)
-    unsigned long long* const bk_u = (unsigned long long*)(lds32 + o_books + 4);    // steps below T = 1 since the last minimum
+    // steps with T < 1 so far (anneal()'s early stop, see emin_l0): read and written once per chunk, so an LDS word
+    // pair rather than a loop-carried scalar
+    unsigned long long* const below1_total = (unsigned long long*)(lds32 + ((o_flag + 4u + 1u) & ~1u));
     // Which of the two waves steps and which feeds.  The dispatcher puts the two waves of a workgroup on different
     // SIMDs and, with four workgroups per CU, two waves on every SIMD -- but not always one wave 0 and one wave 1: now
     // and then a SIMD gets the wave 0 of two workgroups.  Two stepping waves on one SIMD run ~20 % slower each, and a
@@ -171,8 +169,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
             for (uint32_t i = lane; i < K * D; i += kWave) eta_l[i] = eta_g[i];
         if (lane == 0) {
             *stop_flag = 0;
-            *bk_emin = INFINITY;  // metropolis_hasting.cc:75
-            *bk_u = 0;
+            *below1_total = 0;
         }
     }
     // The stepping wave shares its SIMD with the feeder wave of another chain (four chains per CU): it is the
@@ -200,8 +197,10 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     const double T_const = (double)p.kw0;  // CT: constant schedule (metropolis_hasting.cc:25-28)
     // m_r <= E: with E + maxdeg inside the log_q table no step can use the closed-form tier of the hot path
     const bool never_direct = (p.rowptr[n] >> 1) + p.maxdeg <= (uint32_t)kQNmax;
-    // the early-stop bookkeeping can only ever fire below T = 1 (a scalar word, not a lane mask: one s_cmp to test)
-    const uint32_t track_min = (uint32_t)__builtin_amdgcn_readfirstlane((!CT || T_const < 1.) ? 1 : 0);
+    // the early-stop bookkeeping can only ever fire below T = 1, and only if steps_await can be reached within the call
+    // (the counter starts at 0 and gains at most 1 per step) -- a scalar word, not a lane mask: one s_cmp to test
+    const uint32_t track_min =
+        (uint32_t)__builtin_amdgcn_readfirstlane(((!CT || T_const < 1.) && p.steps_await <= p.duration) ? 1 : 0);
     // constants of the hot step (log_q closed form, accept filter)
     BISBM_PIN(c_l2e, 0x1.71547652b82fep+0);        // log2(e)
     BISBM_PIN(c_tol, 1e-5);                        // accept filter margin
@@ -213,6 +212,12 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     // inside the lane-0 region of an accepted step (a vector add under the execution mask, no LDS round trip).
     double cum_l0 = sc->cum_dS;
     unsigned long long acc_l0 = 0;
+    // anneal()'s early stop (metropolis_hasting.cc:75-76,85-98): `u`, the number of steps with T < 1 since entropy_ last
+    // reached a new minimum, is only looked at when a sweep ends.  Kept as u = (steps with T < 1 so far) - (steps with
+    // T < 1 before the step of the last minimum): the first count advances once per chunk, the second (and the minimum
+    // itself) lives in lane 0's registers and is touched by accepted moves only -- a rejected step does nothing.
+    double emin_l0 = INFINITY;
+    unsigned long long mark_l0 = 0;
     double rate = 0.;
     bool stopped = false;
 #ifdef BISBM_STAMPS
@@ -373,26 +378,19 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                 if (k_own == 1u || deg_l == 0u || deg_l > kRowCap || (CT && T_const == 0.) || never_direct)
                     prop_l |= 0x80000000u;
 
-                // anneal()'s bookkeeping after a step, metropolis_hasting.cc:85-94
-                // (every lane reads and writes the same LDS words with the same values; the sum of accepted dS and the
-                // accepted count are bumped by lane 0 where a step is accepted)
-                auto book_min_on = [&](bool ok, double T) {
-                    wfence();
-                    const double c = readlane(cum_l0, 0u);
-                    if (ok && c < *bk_emin) {
-                        *bk_emin = c;
-                        *bk_u = 0;
-                    }
-                    wfence();
-                    if (T < 1.) *bk_u = *bk_u + 1;
-                    wfence();
-                };
-                auto book_min = [&](bool ok, double T) {
-                    if (track_min != 0u) book_min_on(ok, T);
+                // anneal()'s bookkeeping, metropolis_hasting.cc:85-94, see emin_l0 above
+                const unsigned long long below1_mask =
+                    track_min != 0u ? __builtin_amdgcn_ballot_w64(lane < cnt && T_l < 1.) : 0ull;
+                const unsigned long long below1_before = track_min != 0u ? *below1_total : 0ull;
+                auto new_minimum = [&](uint32_t q) {  // after the accepted move of step q (cum_l0 is updated)
+                    const unsigned long long before =
+                        below1_before + (unsigned long long)__builtin_popcountll(below1_mask & ((1ull << q) - 1ull));
+                    const bool better = cum_l0 < emin_l0;  // (:87-90)
+                    emin_l0 = better ? cum_l0 : emin_l0;
+                    mark_l0 = better ? before : mark_l0;
                 };
                 auto book = [&](bool ok, double T) {
                     if (ok && lane == 0) acc_l0 += 1;
-                    book_min(ok, T);
                 };
 
                 // ---- any step (all the rare cases included): the definition the hot path below specialises ----
@@ -524,6 +522,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                         }
                         if (lane == 0) cum_l0 += dS;  // :500
                         wfence();
+                        if (track_min != 0u) new_minimum(q);
                     }
                     book(ok, T);
                 };
@@ -575,7 +574,6 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     if (s_loc == r_loc) {  // r == s: dS = 0, accepted as is unless T == 0; nothing changes (:109-112, :49-50)
                         const bool ok = n_r_r != 1 && (CT || T != 0.);
                         if (ok && lane == 0) acc_l0 += 1;
-                        if constexpr (TM) book_min_on(ok, T);
                         return;
                     }
                     const uint32_t r = own_base + r_loc, s = own_base + s_loc;
@@ -646,10 +644,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     const double dS = K32 ? butterfly_sum_low32(d) : butterfly_sum(d);
                     FSTAMP_STEP(6);
                     if (!CT && T == 0.) {  // the greedy tail of a cooling schedule (:49-50): dS < 0 decides
-                        if (!(dS < 0.) || n_r_r == 1) {
-                            if constexpr (TM) book_min_on(false, T);
-                            return;
-                        }
+                        if (!(dS < 0.) || n_r_r == 1) return;
                     } else {
                         // accept (:47-61): u accu0 < accu1 exp(-dS/T), decided on a 1e-7-accurate exponential unless
                         // the two sides are within 1e-5 of each other (then the exact one decides)
@@ -659,16 +654,10 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                         const unsigned long long b_lt = __builtin_amdgcn_ballot_w64(lhs < est);
                         const unsigned long long b_far = __builtin_amdgcn_ballot_w64(fabs(lhs - est) > c_tol * est);
                         FSTAMP_STEP(7);
-                        if ((b_lt | ~b_far) == 0) {  // clearly rejected
-                            if constexpr (TM) book_min_on(false, T);
-                            return;
-                        }
+                        if ((b_lt | ~b_far) == 0) return;  // clearly rejected
                         unsigned long long b_acc = b_lt;
                         if (__builtin_expect(b_far == 0, 0)) b_acc = __builtin_amdgcn_ballot_w64(lhs < accu1 * exp(z));
-                        if (b_acc == 0 || n_r_r == 1) {  // (:467-471: veto after the draw)
-                            if constexpr (TM) book_min_on(false, T);
-                            return;
-                        }
+                        if (b_acc == 0 || n_r_r == 1) return;  // (:467-471: veto after the draw)
                     }
                     // ---- apply_mcmc_moves, blockmodel.cc:461-503 ----
                     const uint32_t v = readlane(v_l, q);
@@ -689,12 +678,17 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     }
                     wfence();
                     FSTAMP_STEP(8);
-                    if constexpr (TM) book_min_on(true, T);
+                    if constexpr (TM) new_minimum(q);
                 };
                 if (track_min != 0u) {
                     for (uint32_t q = 0; q < cnt; ++q) step(std::true_type{}, q);
                 } else {
                     for (uint32_t q = 0; q < cnt; ++q) step(std::false_type{}, q);
+                }
+                if (track_min != 0u) {
+                    wfence();
+                    *below1_total = below1_before + (unsigned long long)__builtin_popcountll(below1_mask);
+                    wfence();
                 }
             };
 
@@ -717,7 +711,11 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
 
         ++sweeps_total;
         sweeps_done = sweep + 1;
-        if (is_main && lane == 0 && *bk_u >= p.steps_await) *stop_flag = 1;  // metropolis_hasting.cc:96-98
+        {  // metropolis_hasting.cc:96-98 (without the bookkeeping u stays 0)
+            const unsigned long long mark = ((unsigned long long)readlane((uint32_t)(mark_l0 >> 32), 0u) << 32) | readlane((uint32_t)mark_l0, 0u);
+            const unsigned long long u_now = track_min != 0u ? *below1_total - mark : 0ull;
+            if (is_main && lane == 0 && u_now >= p.steps_await) *stop_flag = 1;
+        }
         __syncthreads();
         if (__builtin_amdgcn_readfirstlane((int)*stop_flag)) {  // (scalar: the sweep loop has no divergent exit)
             rate = (double)acc_l0 / (double)((sweep + 1) * (uint64_t)n);

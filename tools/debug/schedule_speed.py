@@ -10,6 +10,6 @@ for name, sched, kw, dur in [("constant", pkg.constant_schedule, [1.0], n), ("co
                              ("exponential", "exponential", [1.0, 0.99999999], 3 * n), ("linear", "linear", [1.0, 1e-9], 3 * n),
                              ("logarithmic", "logarithmic", [10.0, 2.0], 3 * n), ("abrupt_cool", "abrupt_cool", [1.5e6], 3 * n),
                              ("constant T=0.5", pkg.constant_schedule, [0.5], 3 * n), ("exponential 6 sweeps", "exponential", [1.0, 0.99999999], 6 * n)]:
-    r = mh.anneal(m, sched, kw, dur, 1 << 60)
+    r = mh.anneal(m, sched, kw, dur, dur if len(sys.argv) > 1 and sys.argv[1] == "await" else 1 << 60)  # "await": early-stop bookkeeping on
     ms, upd = m.last_sweep_timing()
     print("%-22s %8.1f ms for %d sweeps -> %.3f us per step per chain, acceptance %.3f" % (name, ms, dur // n, ms * 1e3 / (dur), float(np.mean(r))), flush=True)
