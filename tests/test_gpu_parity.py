@@ -212,6 +212,37 @@ def test_either_wave_can_step(roles, monkeypatch):
         assert_state_equal(g, o, c)
 
 
+def test_early_stop_fires_in_production_kernel():
+    """anneal() returns at the end of the sweep in which `steps_await` steps with T < 1 have passed without a new minimum
+    (metropolis_hasting.cc:85-98).  The production kernel keeps that count as a difference of two counts; the run must
+    stop in the same sweep as the oracle's literal bookkeeping, for several chains and schedules."""
+    name, na, nb, ne, ka, kb, eps, hubs, iso = next(c for c in CASES if c[0] == "direct_tier")
+    rowptr, col = _random_graph(11, na, nb, ne, ka, kb, hubs, iso)
+    labels = O.contiguous_labels(na, nb, ka, kb)
+    n, chains, first = na + nb, 5, 21
+    g = gpu_model(rowptr, col, na, nb, ka, kb, eps, labels, n_chains=chains, rng="philox", seed=4242, first_chain_id=first)
+    g.shuffle_bisbm()
+    mh = B.MetropolisHasting()
+    runs = [("exponential", [2.0, 0.9999], 40 * n, n // 2), ("abrupt_cool", [1.5 * n], 40 * n, n // 3),
+            ("constant", [0.25], 40 * n, n // 4), ("linear", [1.2, 1.0 / (2 * n)], 40 * n, 0)]
+    got = []
+    for sched, kw, dur, await_ in runs:
+        rates = mh.anneal(g, sched, kw, dur, await_)
+        acc, sw = g.last_counts()
+        got.append((rates.copy(), acc.copy(), sw.copy()))
+    stopped_early = 0
+    for c in range(chains):
+        o = O.OracleModel(rowptr, col, na, nb, ka, kb, eps, labels)
+        o.seed_philox(4242, first + c)
+        o.shuffle_bisbm()
+        for (sched, kw, dur, await_), (rates, acc, sw) in zip(runs, got):
+            assert o.anneal(sched, kw, dur, await_) == rates[c], (sched, c)
+            assert acc[c] == o.last_accepted and sw[c] == o.last_sweeps, (sched, c)
+            stopped_early += int(o.last_sweeps < dur // n)
+        assert_state_equal(g, o, c)
+    assert stopped_early >= 3 * chains  # (the stop did fire: every run but possibly one per chain ended before its duration)
+
+
 def test_config2_256_chains_philox():
     """BASELINE config 2: n_1000, Ka=4, Kb=6, 256 independent chains, constant T=1."""
     rowptr, col, na, nb = O.load_graph("n_1000")
