@@ -2,7 +2,11 @@
 """bench.py -- node-label MH updates/s of the sweep engine on BASELINE.json's headline workload.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+With N > 1 and no launcher in the environment (RANK / WORLD_SIZE unset) this process starts the N ranks itself
+-- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...` as a
+child, before anything here has touched the GPU -- forwards rank 0's JSON line and exits with the children's
+code.  Under a launcher (RANK / WORLD_SIZE set) it is one rank.
 
 Workload (configs[2] of BASELINE.json, the configuration the metric is quoted on): synthetic planted
 bipartite graph N_a = N_b = 5e5, E = 1e7, Ka = Kb = 32 (graph seed 1), 1024
@@ -10,16 +14,18 @@ independent chains PER GPU, constant T = 1, epsilon = 1, randomised start ("marg
 One step = one sweep = one pass of the hot path (n node updates) over every chain = one sweep-kernel
 launch.  Inputs (CSR, labels, tables) are resident in HBM before the timed region starts.
 Chains shard over GPUs with no collective in the sweep path (scaling = "weak": 1024 chains per GPU);
-the RCCL pooling of per-chain sums runs after the timed region.
+the RCCL pooling of per-chain sums and of the marginal histogram runs after the timed region.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: sweep_kernel, HBM-bound, measured
-with HIP events on the launch stream) and `cpu_baseline` (the oracle restatement timed on one host
-core on a bounded sample of the same workload; N = 1 only).
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: sweep_fast_kernel; the HBM figure SURVEY 8(d)
+defines, the instruction-issue ceiling the counters support, and the measured HBM traffic) and `cpu_baseline` (the
+oracle restatement timed on the host cores on a bounded sample of the same workload; N = 1 only).
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,6 +35,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md chip table: 8.0 TB/s spec (6.29 TB/s measured copy)
+N_SIMDS = 256 * 4      # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md chip table)
+ISSUE_CYCLES = 4.0     # a wave64 VALU instruction occupies its SIMD for 4 cycles (same guide, cycle constants)
 
 
 def b_alg_per_update(n, n_edges, label_bytes=1):
@@ -36,31 +44,7 @@ def b_alg_per_update(n, n_edges, label_bytes=1):
     return 8.0 + (4.0 + label_bytes) * (2.0 * n_edges / n) + 2.0 * label_bytes
 
 
-def cpu_baseline(rowptr, col, na, nb, ka, kb, eps, labels, seconds_budget=20.0):
-    """The oracle (kind "port": bit-exact with the reference in compat mode, see tests) timed on ONE
-    host core: anneal() only, init excluded, constant T = 1 after a randomised start."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
-    n = na + nb
-    m = O.OracleModel(rowptr, col, na, nb, ka, kb, eps, labels)
-    m.seed_compat(42, 43)
-    m.shuffle_bisbm()
-    t0 = time.perf_counter()
-    m.anneal("constant", [1.0], n, 1 << 60)  # one sweep to size the sample
-    dt1 = time.perf_counter() - t0
-    extra = int(max(0, min(50, (seconds_budget - dt1) // max(dt1, 1e-9))))
-    steps, dt = n, dt1
-    if extra > 0:
-        t0 = time.perf_counter()
-        m.anneal("constant", [1.0], extra * n, 1 << 60)
-        dt += time.perf_counter() - t0
-        steps += extra * n
-    return {"value": steps / dt, "unit": "updates/s", "cores": 1, "kind": "port",
-            "sample": "oracle/bisbm_oracle.c (mt19937-compat), 1 chain, %d sweeps of the same graph, "
-                      "anneal() wall time only, %.1f s" % (steps // n, dt)}
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -74,9 +58,168 @@ def main():
     ap.add_argument("--ka", type=int, default=32)
     ap.add_argument("--kb", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra legs after the timed region (equilibrated-start figure, pooling timings)")
     ap.add_argument("--shuffle-ids", action="store_true",
                     help="custom workload: renumber the nodes of each type at random (ids that carry no structure)")
-    args = ap.parse_args()
+    ap.add_argument("--no-reorder", action="store_true",
+                    help="with --shuffle-ids: do not run the ingest-time locality reordering pass")
+    ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)  # internal: one CPU-baseline process
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------- launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """--gpus N > 1 outside a launcher: start the N ranks as children (never re-exec: this process has not touched the
+    GPU and never will), forward rank 0's JSON line, return the children's exit code."""
+    pkg = importlib.import_module("bipartitesbm-mcmc_amd")  # ctypes + numpy only: no HIP call
+    if not os.path.exists(pkg.LIB_PATH):
+        pkg.build()  # once, here, so the ranks do not race to compile it
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        s = out.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+        sys.stderr.write("bench.py: the ranks exited without a result line\n")
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------- workload
+def make_graph(args, pkg, syn):
+    na, nb, ka, kb, E = args.na, args.nb, args.ka, args.kb, args.edges
+    n = na + nb
+    a, b = syn.planted_edges(na, nb, E, ka, kb, seed=1)
+    if args.shuffle_ids:
+        rs = np.random.default_rng(7)
+        pa, pb = rs.permutation(na).astype(a.dtype), rs.permutation(nb).astype(b.dtype)
+        a, b = pa[a], pb[b - na] + na
+    rowptr, col = pkg.edge_to_adj((a, b), n)
+    return rowptr, col
+
+
+# ----------------------------------------------------------------------------------------------- CPU baseline
+# The reference's own binary cannot be built on this image (Boost) -- SURVEY section 6 timed it once in the build
+# container with a header shim: 2.27e5 updates/s on one core of an "Intel Xeon Processor @ 2.10GHz" at this workload
+# (22.0 s per 5 sweeps), where the port (the oracle, same flags) runs 9.9e5 updates/s.
+REF_PROBE = {"reference_updates_per_s": 2.27e5, "port_updates_per_s_same_cpu": 9.9e5,
+             "cpu": "Intel Xeon Processor @ 2.10GHz (build container, 1 core)",
+             "source": "SURVEY.md section 6 [probe] (reference TUs -O3, anneal() only, 5 sweeps) and DESIGN.md section 7"}
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_worker(args):
+    """One process of the CPU baseline: the oracle (kind "port": bit-exact with the reference's recorded runs in compat
+    mode, see tests) on one core: anneal() only, init excluded, constant T = 1 after a randomised start."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    syn = importlib.import_module("bipartitesbm-mcmc_amd.synthetic")
+    na, nb, ka, kb = args.na, args.nb, args.ka, args.kb
+    n = na + nb
+    a, b = syn.planted_edges(na, nb, args.edges, ka, kb, seed=1)
+    rowptr, col = O.edge_to_csr(a, b, n)
+    del a, b
+    m = O.OracleModel(rowptr, col, na, nb, ka, kb, 1.0, syn.contiguous_labels(na, nb, ka, kb))
+    m.seed_compat(42 + int(os.environ.get("BISBM_CPU_WORKER_INDEX", "0")), 43)
+    m.shuffle_bisbm()
+    print("ready", flush=True)
+    sys.stdin.readline()  # all workers start their timed part together
+    budget = args.cpu_worker
+    t0 = time.perf_counter()
+    m.anneal("constant", [1.0], n, 1 << 60)  # one sweep to size the sample
+    dt = time.perf_counter() - t0
+    steps = n
+    extra = int(max(0, min(50, (budget - dt) // max(dt, 1e-9))))
+    if extra > 0:
+        t0 = time.perf_counter()
+        m.anneal("constant", [1.0], extra * n, 1 << 60)
+        dt += time.perf_counter() - t0
+        steps += extra * n
+    print(json.dumps({"steps": steps, "seconds": dt}), flush=True)
+
+
+def cpu_baseline(n, seconds_budget=18.0):
+    """`cores` independent single-chain processes of the oracle, one per host core, timed together (the reference is
+    single-threaded: its multi-core figure is one process per core).  value = their summed rate."""
+    cores = max(1, min(os.cpu_count() or 1, 16))
+    try:
+        cores = max(1, min(cores, len(os.sched_getaffinity(0))))
+    except (AttributeError, OSError):
+        pass
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(seconds_budget)] + \
+          [a for a in sys.argv[1:] if a not in ("--no-extras",)]
+    procs = [subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True,
+                              env=dict(os.environ, BISBM_CPU_WORKER_INDEX=str(i), OMP_NUM_THREADS="1"))
+             for i in range(cores)]
+    for p in procs:
+        assert p.stdout.readline().strip() == "ready"
+    for p in procs:
+        p.stdin.write("go\n")
+        p.stdin.flush()
+    res = []
+    for p in procs:
+        res.append(json.loads(p.stdout.readline()))
+        p.wait()
+    per_core = [r["steps"] / r["seconds"] for r in res]
+    total = float(sum(per_core))
+    one = float(np.median(per_core))
+    return {"value": total, "unit": "updates/s", "cores": cores, "kind": "port",
+            "per_core": one, "cpu": _cpu_model(),
+            "sample": "oracle/bisbm_oracle.c (mt19937-compat), %d independent 1-chain processes (one per core), %d-%d "
+                      "sweeps each of the same graph, anneal() wall time only, %.1f s" % (
+                          cores, min(r["steps"] for r in res) // n, max(r["steps"] for r in res) // n,
+                          max(r["seconds"] for r in res)),
+            "ratio_to_reference": REF_PROBE["port_updates_per_s_same_cpu"] / REF_PROBE["reference_updates_per_s"],
+            "reference_estimate_updates_per_s": total * REF_PROBE["reference_updates_per_s"] / REF_PROBE["port_updates_per_s_same_cpu"],
+            "reference_probe": REF_PROBE}
+
+
+# ----------------------------------------------------------------------------------------------- main
+def profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f)
+    return None
+
+
+def main():
+    args = parse_args()
+    if args.cpu_worker > 0:
+        return cpu_worker(args)
+    in_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not in_launcher:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -84,7 +227,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     # one process per GPU; BISBM_BENCH_BACKEND=gloo lets the multi-rank path be rehearsed on a one-GPU box
@@ -103,18 +246,21 @@ def main():
     pkg = importlib.import_module("bipartitesbm-mcmc_amd")
     syn = importlib.import_module("bipartitesbm-mcmc_amd.synthetic")
     if not os.path.exists(pkg.LIB_PATH):
+        if world > 1:
+            raise SystemExit("libbisbm_hip.so is missing: build it once before starting the ranks (__graft_entry__.build())")
         pkg.build()
 
     na, nb, ka, kb, E = args.na, args.nb, args.ka, args.kb, args.edges
     n = na + nb
-    a, b = syn.planted_edges(na, nb, E, ka, kb, seed=1)
-    if args.shuffle_ids:
-        import numpy as np
-        rs = np.random.default_rng(7)
-        pa, pb = rs.permutation(na).astype(a.dtype), rs.permutation(nb).astype(b.dtype)
-        a, b = pa[a], pb[b - na] + na
-    rowptr, col = pkg.edge_to_adj((a, b), n)
-    del a, b
+    rowptr, col = make_graph(args, pkg, syn)
+    reorder = None
+    if args.shuffle_ids and not args.no_reorder and hasattr(pkg, "locality_order"):
+        # ingest-time reordering pass for ids that carry no structure: the engine runs on the
+        # renumbered graph; labels are mapped back at the boundary
+        t0 = time.perf_counter()
+        reorder = pkg.locality_order(rowptr, col, na, nb)
+        rowptr, col = reorder.apply(rowptr, col)
+        reorder_s = time.perf_counter() - t0
     labels = syn.contiguous_labels(na, nb, ka, kb)
     shard = pkg.ChainShard(args.chains * world, rank=rank, world_size=world)
     model = pkg.BlockModel(labels, syn.types_vector(na, nb), ka + kb, ka, kb, 1.0, (rowptr, col),
@@ -131,9 +277,7 @@ def main():
     # Spin-up, not part of the protocol's W + K steps: the chains simply run on through a few throw-away sweeps -- at
     # least --spinup of them, then until two launches in a row are within 5 % of the fastest one seen -- so the warm-up
     # and timed sweeps are later sweeps of the same chains (slightly slower ones: the accepted fraction and with it
-    # the speed drift down by ~0.5 % per sweep).  History: before the kernel assigned its stepping waves to SIMDs
-    # itself, one launch in three or so came out 22 % slow (two stepping waves on one SIMD);
-    # the settle test is the guard that remains from that.
+    # the speed drift down by ~0.5 % per sweep).
     verbose = bool(os.environ.get("BISBM_BENCH_VERBOSE"))
 
     def note(what):
@@ -142,27 +286,31 @@ def main():
                 what, model.last_sweep_timing()[0], float(model.last_counts()[0].sum()) / (n * shard.n_local),
                 time.time()), file=sys.stderr, flush=True)
 
+    def sweep():
+        mh.anneal(model, pkg.constant_schedule, [1.0], n, 1 << 60)  # blocks until the sweep kernel is done
+
     spin_ms = []
     while args.spinup and len(spin_ms) < args.spinup + 6:
-        mh.anneal(model, pkg.constant_schedule, [1.0], n, 1 << 60)
+        sweep()
         note("spin-up")
         spin_ms.append(model.last_sweep_timing()[0])
         if len(spin_ms) >= max(args.spinup, 2) and max(spin_ms[-2:]) <= 1.05 * min(spin_ms):
             break
     for _ in range(args.warmup):
-        mh.anneal(model, pkg.constant_schedule, [1.0], n, 1 << 60)
+        sweep()
         note("warm-up")
     sync()
     t0 = time.perf_counter()
     kernel_ms, updates = 0.0, 0
     for _ in range(args.steps):
-        mh.anneal(model, pkg.constant_schedule, [1.0], n, 1 << 60)  # blocks until the sweep kernel is done
+        sweep()
         ms, upd = model.last_sweep_timing()
         note("timed")
         kernel_ms += ms
         updates += upd
     sync()
     elapsed = time.perf_counter() - t0
+    accepted_frac = float(model.last_counts()[0].sum()) / (n * shard.n_local)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -173,13 +321,54 @@ def main():
     else:
         total_updates = updates
 
-    # pooling epilogue (outside the timed region): RCCL all_gather of the per-chain sums
+    # ---- after the timed region -------------------------------------------------------------------------------------
+    extras = {}
+    # pooling epilogue: RCCL all_gather of the per-chain sums
     cum = torch.from_numpy(model.get_entropy()).to(coll_device).reshape(-1, 1)
+    sync()
     t1 = time.perf_counter()
     allcum = shard.all_gather_chain_values(cum)
     torch.cuda.synchronize()
     pool_ms = (time.perf_counter() - t1) * 1e3
     assert allcum.shape[0] == args.chains * world and bool(torch.isfinite(allcum).all())
+    if world > 1 and not args.no_extras:
+        extras["pool_all_gather_ms"] = pool_ms
+        # marginals: one sample of every chain into a device histogram, pooled by reduce_scatter over node ranges
+        # (128 MB of counts at this workload, 1 GB at config 5's)
+        dev = torch.device("cuda", device_index)
+        counts = torch.zeros((n, model.kmax), dtype=torch.int32, device=dev)
+        model.marginals_accumulate(counts.data_ptr())
+        torch.cuda.synchronize()
+        send = counts if backend == "nccl" else counts.cpu()
+        sync()
+        t1 = time.perf_counter()
+        lab = shard.map_labels(send, na, ka)
+        if backend == "nccl":
+            torch.cuda.synchronize()
+        extras["pool_marginals_reduce_scatter_argmax_all_gather_ms"] = (time.perf_counter() - t1) * 1e3
+        extras["pool_marginals_bytes"] = int(counts.numel() * 4)
+        assert lab.shape[0] == n
+        del counts, send
+
+    # the same workload from an equilibrated start: every chain on the planted partition (the posterior mode of this
+    # generator), a few sweeps to settle, then timed -- the regime a long marginalize run lives in
+    equil = None
+    if not args.no_extras:
+        model.set_memberships(labels)
+        model.init_bisbm()
+        for _ in range(3):
+            sweep()
+        sync()
+        ems, eupd = 0.0, 0
+        for _ in range(3):
+            sweep()
+            ms, upd = model.last_sweep_timing()
+            ems += ms
+            eupd += upd
+        equil = {"updates_per_s_per_gpu": eupd / (ems / 1e3), "avg_launch_ms": ems / 3,
+                 "accepted_fraction": float(model.last_counts()[0].sum()) / (n * shard.n_local),
+                 "what": "same graph and chains, started on the planted partition (near the posterior mode), 3 sweeps "
+                         "to settle, 3 timed (kernel time)"}
 
     if rank == 0:
         per_launch_updates = updates / max(args.steps, 1)
@@ -187,15 +376,37 @@ def main():
         balg = b_alg_per_update(n, E)
         achieved = balg * per_launch_updates / avg_kernel_s / 1e9
         default_cfg = (na, nb, E, ka, kb, args.chains) == (500_000, 500_000, 10_000_000, 32, 32, 1024) and not args.shuffle_ids
-        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
-        # WRITE_SIZE, separate runs of this same command); only quoted for the workload they were measured on
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if default_cfg and os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            traffic = tj["bytes_per_update"] * per_launch_updates
-            traffic_src = "profiles/r01_traffic.json (FETCH_SIZE+WRITE_SIZE, %.0f B per update)" % tj["bytes_per_update"]
+        # HBM bytes per launch and instructions per update from the PMC passes committed under profiles/ (rocprofv3
+        # --pmc, separate runs of this same command); only quoted for the workload they were measured on
+        traffic, traffic_src, issue, steady = None, None, None, None
+        if default_cfg:
+            tj = profile_json("r02_traffic.json") or profile_json("r01_traffic.json")
+            if tj:
+                traffic = tj["bytes_per_update"] * per_launch_updates
+                traffic_src = "%s (FETCH_SIZE+WRITE_SIZE, %.0f B per update%s)" % (
+                    tj.get("_file", "profiles/*_traffic.json"), tj["bytes_per_update"],
+                    ", calibration: " + tj["calibration"] if "calibration" in tj else "")
+            ij = profile_json("r02_issue.json")
+            if ij:
+                # Instruction-issue ceiling: a lone stepping wave per SIMD issues one instruction per >= 4 cycles, so
+                # updates/s <= SIMDs x clock / (instructions per update x 4 cycles)
+                ipu, clk = ij["instructions_per_update"], ij["clock_ghz"]
+                peak = N_SIMDS * clk * 1e9 / (ipu * ISSUE_CYCLES)
+                ups = per_launch_updates / avg_kernel_s
+                issue = {"instructions_per_update": ipu, "valu_per_update": ij.get("valu_per_update"),
+                         "cycles_per_instruction": ISSUE_CYCLES, "simds": N_SIMDS, "clock_ghz": clk,
+                         "peak_updates_per_s": peak, "achieved_updates_per_s": ups, "frac": ups / peak,
+                         "source": ij.get("_file", "profiles/r02_issue.json")}
+            steady = profile_json("r02_steady_state.json")
+        roofline = {
+            "bound": "hbm", "kernel": "sweep_fast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "alg_bytes_per_update": balg, "updates_per_launch": per_launch_updates,
+            "avg_launch_ms": avg_kernel_s * 1e3,
+            "note": "bound/achieved/frac are the SURVEY 8(d) HBM figure (algorithmic bytes); by its counters the "
+                    "kernel is instruction-issue/latency-bound, not HBM-bound: see issue_bound",
+            "issue_bound": issue,
+        }
         out = {
             "metric": "node-label MH updates/s",
             "value": total_updates / elapsed,
@@ -214,21 +425,22 @@ def main():
                 "workload": ("BASELINE configs[2]: " if default_cfg else "custom: ")
                 + "planted bipartite N_a=%d N_b=%d E=%d Ka=%d Kb=%d, %d chains/GPU, constant T=1, eps=1, "
                   "randomised start, Philox mode%s" % (na, nb, E, ka, kb, args.chains,
-                                                       ", node ids renumbered at random" if args.shuffle_ids else ""),
+                                                       (", node ids renumbered at random" +
+                                                        (", locality reordering at ingest (%.1f s)" % reorder_s if reorder else ""))
+                                                       if args.shuffle_ids else ""),
                 "chains_total": args.chains * world, "step": "one sweep (n node updates) of every chain",
                 "spinup_sweeps_before_warmup": len(spin_ms),
+                "accepted_fraction_last_timed_sweep": accepted_frac,
                 "parallelism": "chains sharded, no collective in the sweep path",
             },
-            "roofline": {
-                "bound": "hbm", "kernel": "sweep_fast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "alg_bytes_per_update": balg, "updates_per_launch": per_launch_updates,
-                "avg_launch_ms": avg_kernel_s * 1e3,
-            },
-            "pool_all_gather_ms": pool_ms,
+            "roofline": roofline,
+            "equilibrated_start": equil,
+            "steady_state": steady,
         }
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(rowptr, col, na, nb, ka, kb, 1.0, labels)
+            del model
+            out["cpu_baseline"] = cpu_baseline(n)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -1047,6 +1047,12 @@ static size_t propose_philox(orc_model *m, size_t v, double u_idx, double u_R, d
     return hi - 1;
 }
 
+/* test hook: the Philox-mode proposal for given uniforms (tests enumerate them to get the exact target distribution
+ * and compare it with blockmodel.cc:619-628's R_t/K + (1 - R_t) m[t][s]/m_r[t]) */
+size_t orc_propose_philox(orc_model *m, size_t v, double u_idx, double u_R, double u_tgt) {
+    return propose_philox(m, v, u_idx, u_R, u_tgt);
+}
+
 /* metropolis_hasting.cc:42-62 */
 static int step_compat(orc_model *m, size_t v, double temperature) {
     size_t s = propose_compat(m, v);

@@ -1,0 +1,112 @@
+"""Seeded graphs shared by the CPU and the GPU test modules (no GPU, no product code: numpy + the oracle's CSR)."""
+import importlib
+
+import numpy as np
+
+import oracle_lib as O
+
+SYN = importlib.import_module("bipartitesbm-mcmc_amd.synthetic")
+
+
+def random_graph(seed, na, nb, ne, ka, kb, hubs=0, isolated=0):
+    a, b = SYN.planted_edges(na - isolated, nb - isolated, ne, max(ka, 1), max(kb, 1), seed=seed)
+    b = b - (na - isolated) + na  # keep b ids in [na, na+nb-isolated)
+    if hubs:  # a few nodes with degree ~150 (several rounds of the feeder's walk); hubs == 1: one node with degree > 255
+        rng = np.random.default_rng(seed + 100)
+        n_hub_edges = 150 * hubs if hubs > 1 else 600
+        ha = rng.integers(0, hubs, n_hub_edges).astype(np.uint64)
+        hb = (na + rng.integers(0, nb - isolated, n_hub_edges)).astype(np.uint64)
+        a, b = np.concatenate([a, ha]), np.concatenate([b, hb])
+    rowptr, col = O.edge_to_csr(a, b, na + nb)
+    return rowptr, col
+
+
+CASES = [
+    # name, na, nb, edges, ka, kb, eps, hubs, isolated
+    ("tiny", 12, 9, 40, 3, 2, 0.5, 0, 0),
+    ("ka1", 40, 30, 300, 1, 4, 1.0, 0, 0),
+    ("hubs_isolated", 300, 200, 3000, 5, 7, 1.0, 3, 4),
+    ("huge_hub", 300, 200, 3000, 5, 7, 1.0, 1, 0),    # degree > 255: beyond the byte counters of the feeder's walk
+    ("wideK", 400, 300, 6000, 70, 3, 2.0, 0, 0),       # K_type > 64: chunked lane loops
+    ("big_m_r", 150, 150, 60000, 2, 3, 1.0, 0, 0),     # m_r > 10^4: log_q_approx on the device
+    # production kernel's hot step: m_r > 10^4 and k / sqrt(n) > 24 (closed-form log_q tier), K <= 32 ...
+    ("direct_tier", 20000, 20000, 100000, 2, 2, 1.0, 0, 0),
+    # ... the same with both block counts > 32 (six-level scans and sums) ...
+    ("direct_tier_wide", 72000, 72000, 216000, 40, 33, 1.0, 0, 0),
+    # ... and k / sqrt(n) around 23: the hot step falls back to the iterated / literal log_q tiers
+    ("mid_tier", 5300, 5300, 26500, 2, 2, 1.0, 0, 0),
+    # ... k / sqrt(n) around 10 (blocks of ~1200 nodes): the converged log_q tier in the hot step
+    ("mid_tier_low", 2400, 2400, 28800, 2, 2, 1.0, 0, 0),
+    # ... and a dense graph (mean degree 40, blocks of 1000 nodes): k / sqrt(n) around 5, the low converged tier
+    ("dense_low_tier", 2000, 2000, 80000, 2, 2, 1.0, 0, 0),
+    # no edges at all: every node has degree 0 (uniform proposals over all K blocks, blockmodel.cc:616-617)
+    ("edgeless", 10, 8, 0, 2, 2, 1.0, 0, 0),
+]
+CASE = {c[0]: c for c in CASES}
+
+
+# ------------------------------------------------------------------ a graph small enough to enumerate
+# 6 + 6 nodes, two planted groups per type (a0-a2 ~ b0-b2, a3-a5 ~ b3-b5) plus two bridging edges and one
+# double edge; K = 2 + 2.  State space: 2^6 x 2^6 label vectors, of which (2^6 - 2)^2 = 3844 have no empty block
+# (apply_mcmc_moves never empties a block, blockmodel.cc:467-471).
+ENUM_NA = ENUM_NB = 6
+ENUM_EDGES = [(0, 6), (0, 7), (1, 6), (1, 8), (2, 7), (2, 8), (2, 6), (3, 9), (3, 10), (4, 9), (4, 11), (5, 10),
+              (5, 11), (5, 9), (1, 9), (4, 7), (0, 6)]
+ENUM_EPS = 1.0
+
+
+def enumerable_graph():
+    a = np.array([e[0] for e in ENUM_EDGES], dtype=np.uint64)
+    b = np.array([e[1] for e in ENUM_EDGES], dtype=np.uint64)
+    rowptr, col = O.edge_to_csr(a, b, ENUM_NA + ENUM_NB)
+    return rowptr, col
+
+
+def enumerable_states():
+    """All label vectors of the enumerable graph with four non-empty blocks, and exp(-S) normalised, S = entropy()
+    (blockmodel.cc:753-787) from the oracle: the stationary distribution of the reference's chain at T = 1."""
+    rowptr, col = enumerable_graph()
+    na, nb = ENUM_NA, ENUM_NB
+    o = O.OracleModel(rowptr, col, na, nb, 2, 2, ENUM_EPS, O.contiguous_labels(na, nb, 2, 2))
+    states, S = [], []
+    for x in range(1, 2 ** na - 1):
+        la = [(x >> i) & 1 for i in range(na)]
+        for y in range(1, 2 ** nb - 1):
+            lab = np.array(la + [2 + ((y >> i) & 1) for i in range(nb)], dtype=np.uint32)
+            o.set_memberships(lab)
+            o.init_bisbm()
+            states.append(state_code(lab))
+            S.append(o.entropy())
+    S = np.array(S)
+    w = np.exp(-(S - S.min()))
+    return np.array(states), w / w.sum(), S
+
+
+def state_code(labels):
+    """12 labels -> integer (bit i = second block of the node's type)."""
+    lab = np.asarray(labels).astype(np.int64)
+    bits = np.concatenate([lab[:ENUM_NA], lab[ENUM_NA:] - 2])
+    return int((bits << np.arange(len(bits))).sum())
+
+
+def chi_square(codes, states, prob, min_expected=8.0):
+    """Pearson chi-square of sampled state codes against `prob` over `states`; states with an expected count below
+    min_expected are pooled into one bin.  Returns (statistic, dof, p_value)."""
+    from scipy import stats
+    n = len(codes)
+    index = {int(s): i for i, s in enumerate(states)}
+    obs = np.zeros(len(states))
+    for c in codes:
+        obs[index[int(c)]] += 1  # KeyError = a state with an empty block was reached
+    exp = prob * n
+    big = exp >= min_expected
+    o = np.concatenate([obs[big], [obs[~big].sum()]])
+    e = np.concatenate([exp[big], [exp[~big].sum()]])
+    if e[-1] < min_expected:  # fold a thin tail into the smallest regular bin
+        j = int(np.argmin(e[:-1]))
+        o[j] += o[-1]
+        e[j] += e[-1]
+        o, e = o[:-1], e[:-1]
+    stat = float(((o - e) ** 2 / e).sum())
+    dof = len(e) - 1
+    return stat, dof, float(stats.chi2.sf(stat, dof))

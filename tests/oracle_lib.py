@@ -91,6 +91,8 @@ def lib():
     L.orc_compute_dS_vertex.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]
     L.orc_transition_ratio.restype = C.c_double
     L.orc_transition_ratio.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, _f64p]
+    L.orc_propose_philox.restype = C.c_size_t
+    L.orc_propose_philox.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_double]
     for name in ("orc_n", "orc_k", "orc_num_edges", "orc_max_degree"):
         getattr(L, name).restype = C.c_size_t
         getattr(L, name).argtypes = [C.c_void_p]
@@ -260,6 +262,9 @@ class OracleModel:
         acc = C.c_double(0)
         dS = self.L.orc_transition_ratio(self.h, v, s, C.byref(acc))
         return dS, acc.value
+
+    def propose_philox(self, v, u_idx, u_R, u_tgt):
+        return self.L.orc_propose_philox(self.h, v, u_idx, u_R, u_tgt)
 
     @property
     def last_accepted(self):
