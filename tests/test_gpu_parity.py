@@ -9,6 +9,7 @@ import os
 import numpy as np
 import pytest
 
+import cases
 import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
@@ -93,40 +94,8 @@ def test_golden_rng_free_state(golden):
 
 
 # ------------------------------------------------------------------ oracle, same seeded inputs
-def _random_graph(seed, na, nb, ne, ka, kb, hubs=0, isolated=0):
-    a, b = SYN.planted_edges(na - isolated, nb - isolated, ne, max(ka, 1), max(kb, 1), seed=seed)
-    b = b - (na - isolated) + na  # keep b ids in [na, na+nb-isolated)
-    if hubs:  # a few nodes with degree ~150 (several rounds of the feeder's walk); hubs == 1: one node with degree > 255
-        rng = np.random.default_rng(seed + 100)
-        n_hub_edges = 150 * hubs if hubs > 1 else 600
-        ha = rng.integers(0, hubs, n_hub_edges).astype(np.uint64)
-        hb = (na + rng.integers(0, nb - isolated, n_hub_edges)).astype(np.uint64)
-        a, b = np.concatenate([a, ha]), np.concatenate([b, hb])
-    rowptr, col = O.edge_to_csr(a, b, na + nb)
-    return rowptr, col
-
-
-CASES = [
-    # name, na, nb, edges, ka, kb, eps, hubs, isolated
-    ("tiny", 12, 9, 40, 3, 2, 0.5, 0, 0),
-    ("ka1", 40, 30, 300, 1, 4, 1.0, 0, 0),
-    ("hubs_isolated", 300, 200, 3000, 5, 7, 1.0, 3, 4),
-    ("huge_hub", 300, 200, 3000, 5, 7, 1.0, 1, 0),    # degree > 255: beyond the byte counters of the feeder's walk
-    ("wideK", 400, 300, 6000, 70, 3, 2.0, 0, 0),       # K_type > 64: chunked lane loops
-    ("big_m_r", 150, 150, 60000, 2, 3, 1.0, 0, 0),     # m_r > 10^4: log_q_approx on the device
-    # production kernel's hot step: m_r > 10^4 and k / sqrt(n) > 24 (closed-form log_q tier), K <= 32 ...
-    ("direct_tier", 20000, 20000, 100000, 2, 2, 1.0, 0, 0),
-    # ... the same with both block counts > 32 (six-level scans and sums) ...
-    ("direct_tier_wide", 72000, 72000, 216000, 40, 33, 1.0, 0, 0),
-    # ... and k / sqrt(n) around 23: the hot step falls back to the iterated / literal log_q tiers
-    ("mid_tier", 5300, 5300, 26500, 2, 2, 1.0, 0, 0),
-    # ... k / sqrt(n) around 10 (blocks of ~1200 nodes): the converged log_q tier in the hot step
-    ("mid_tier_low", 2400, 2400, 28800, 2, 2, 1.0, 0, 0),
-    # ... and a dense graph (mean degree 40, blocks of 1000 nodes): k / sqrt(n) around 5, the low converged tier
-    ("dense_low_tier", 2000, 2000, 80000, 2, 2, 1.0, 0, 0),
-    # no edges at all: every node has degree 0 (uniform proposals over all K blocks, blockmodel.cc:616-617)
-    ("edgeless", 10, 8, 0, 2, 2, 1.0, 0, 0),
-]
+_random_graph = cases.random_graph
+CASES = cases.CASES
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])

@@ -1,0 +1,158 @@
+"""GPU tests (-m gpu) beyond per-chain parity with the oracle:
+  * the production chain's stationary distribution on the enumerable graph (chi-square against exp(-S));
+  * BASELINE configs[3] ("estimate mode": 512 chains on the N = 1e6 graph, 48+48 -> 32+32 blocks through agg_merge
+    stages with greedy sweeps) with a sample of chains equal to their oracle runs;
+  * BASELINE configs[4]'s per-GPU shape (N = 4e6, E = 5e7, Ka = Kb = 64): size-independent properties."""
+import importlib
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+B = importlib.import_module("bipartitesbm-mcmc_amd")
+SYN = importlib.import_module("bipartitesbm-mcmc_amd.synthetic")
+BIG = 1 << 60
+
+
+def gpu_model(rowptr, col, na, nb, ka, kb, eps, labels, **kw):
+    return B.BlockModel(labels, SYN.types_vector(na, nb), ka + kb, ka, kb, eps, (rowptr, col), **kw)
+
+
+def assert_state_equal(g, o, chain=0):
+    assert (g.get_memberships(chain) == o.memberships()).all()
+    assert (g.get_m(chain) == o.m()).all()
+    assert (g.get_m_r(chain) == o.m_r()).all()
+    assert (g.get_n_r(chain) == o.n_r()).all()
+    assert (g.get_eta_rk_(chain) == o.eta()).all()
+
+
+# ------------------------------------------------------------------ stationary distribution of the production chain
+def test_gpu_chains_sample_exp_minus_S():
+    """32768 independent Philox chains of the production kernel on the 6+6-node graph, one sample each after a burn-in
+    from a randomised start, against exp(-S) over the 3844 admissible states (S = entropy(), blockmodel.cc:753-787)
+    -- the same test tests/test_cross_mode.py runs on the oracle in the reference's arithmetic."""
+    rowptr, col = cases.enumerable_graph()
+    na, nb = cases.ENUM_NA, cases.ENUM_NB
+    start = O.contiguous_labels(na, nb, 2, 2)
+    chains, burn_in = 32768, 30
+    g = gpu_model(rowptr, col, na, nb, 2, 2, cases.ENUM_EPS, start, n_chains=chains, rng="philox", seed=4242)
+    g.shuffle_bisbm()
+    B.MetropolisHasting().anneal(g, "constant", [1.0], burn_in * (na + nb), BIG)
+    labs = [g.get_memberships(c) for c in range(chains)]
+    codes = np.array([cases.state_code(l) for l in labs])
+    states, prob, S = cases.enumerable_states()
+    stat, dof, p = cases.chi_square(codes, states, prob)
+    print("GPU philox: chi2 = %.1f on %d dof, p = %.3g" % (stat, dof, p))
+    assert p > 1e-3, (stat, dof, p)
+    w = np.exp(-(S - S.min()) / 1.15)  # power: a slightly wrong target is rejected by the same samples
+    assert cases.chi_square(codes, states, w / w.sum())[2] < 1e-6
+    # and the chains are the oracle's chains
+    for c in (0, 1, 777, chains - 1):
+        o = O.OracleModel(rowptr, col, na, nb, 2, 2, cases.ENUM_EPS, start)
+        o.seed_philox(4242, c)
+        o.shuffle_bisbm()
+        o.anneal("constant", [1.0], burn_in * (na + nb), BIG)
+        assert (o.memberships() == labs[c]).all()
+
+
+# ------------------------------------------------------------------ BASELINE configs[3]: estimate mode
+def test_config4_estimate_mode_512_chains():
+    """The N = 1e6 / E = 1e7 graph, 512 chains, an initial partition of 48 + 48 blocks merged down to 32 + 32 through
+    bisbm_agg_merge stages (blockmodel.cc:109-206; driver loop mcmc_main.cc:425-444: one merge, one greedy sweep per
+    stage), then a sweep at T = 1.  A sample of chains must equal their oracle runs; every chain must be consistent."""
+    na = nb = 500_000
+    n = na + nb
+    a, b = SYN.planted_edges(na, nb, 10_000_000, 32, 32, seed=1)
+    rowptr, col = B.edge_to_adj((a, b), n)
+    del a, b
+    k0 = 48
+    labels = SYN.contiguous_labels(na, nb, k0, k0)
+    chains = 512
+    g = gpu_model(rowptr, col, na, nb, k0, k0, 1.0, labels, n_chains=chains, rng="philox", seed=2024, first_chain_id=100)
+    g.shuffle_bisbm()
+    mh = B.MetropolisHasting()
+    stages = [44, 40, 36, 32]
+    sample = (0, 255, 511)
+    oracles = []
+    for c in sample:
+        o = O.OracleModel(rowptr, col, na, nb, k0, k0, 1.0, labels)
+        o.seed_philox(2024, 100 + c)
+        o.shuffle_bisbm()
+        oracles.append(o)
+    prev = k0
+    for k in stages:
+        g.agg_merge(prev - k, prev - k, 10)
+        assert (g.KA, g.KB) == (k, k)
+        rates = mh.anneal(g, "abrupt_cool", [0.0], n, BIG)  # T = 0: greedy sweep
+        for o, c in zip(oracles, sample):
+            assert o.agg_merge(prev - k, prev - k, 10) == 0
+            ro = o.anneal("abrupt_cool", [0.0], n, BIG)
+            assert ro == rates[c], (k, c, ro, rates[c])
+        prev = k
+    for o, c in zip(oracles, sample):
+        assert_state_equal(g, o, c)
+    ent = g.entropy()
+    for o, c in zip(oracles, sample):
+        assert ent[c] == pytest.approx(o.entropy(), rel=1e-9)
+    # every chain: 32 + 32 non-empty blocks, counts consistent with the labels
+    for c in range(0, chains, 37):
+        lab = g.get_memberships(c)
+        n_r = g.get_n_r(c)
+        assert (np.bincount(lab, minlength=64) == n_r).all() and n_r.min() >= 1
+        assert lab[:na].max() == 31 and lab[na:].min() == 32 and lab[na:].max() == 63
+        assert g.get_m_r(c).sum() == 2 * 10_000_000
+    # the chains go on at T = 1 in the production kernel's K <= 32 variant
+    s0 = g.entropy()
+    cum0 = g.get_entropy()
+    rates = mh.anneal(g, "constant", [1.0], n, BIG)
+    for o, c in zip(oracles, sample):
+        assert o.anneal("constant", [1.0], n, BIG) == rates[c]
+        assert (o.memberships() == g.get_memberships(c)).all()
+    s1 = g.entropy()
+    dcum = g.get_entropy() - cum0  # accepted dS of this call == change of the description length
+    assert np.allclose(s1 - s0, dcum, rtol=1e-9, atol=1e-6 * np.abs(dcum).max())
+    assert ((rates > 0.05) & (rates <= 1.0)).all()
+
+
+# ------------------------------------------------------------------ BASELINE configs[4]: per-GPU shape
+def test_config5_shape_properties():
+    """N_a = N_b = 2e6, E = 5e7, Ka = Kb = 64 (the K > 32 variant of the production kernel, eta in HBM), 16 chains:
+    one sweep keeps the incremental state equal to a recount, block sizes sum to N, and the sum of accepted dS equals
+    the change of the full description length."""
+    na = nb = 2_000_000
+    ka = kb = 64
+    E = 50_000_000
+    a, b = SYN.planted_edges(na, nb, E, ka, kb, seed=1)
+    rowptr, col = B.edge_to_adj((a, b), na + nb)
+    del a, b
+    labels = SYN.contiguous_labels(na, nb, ka, kb)
+    chains = 16
+    g = gpu_model(rowptr, col, na, nb, ka, kb, 1.0, labels, n_chains=chains, rng="philox", seed=5)
+    g.shuffle_bisbm()
+    s0 = g.entropy()
+    rates = B.MetropolisHasting().anneal(g, "constant", [1.0], na + nb, BIG)
+    assert ((rates > 0.3) & (rates <= 1.0)).all()
+    s1 = g.entropy()
+    cum = g.get_entropy()
+    assert np.allclose(s1 - s0, cum, rtol=1e-9, atol=1e-6 * np.abs(cum).max())
+    picks = (0, 7, chains - 1)
+    before = [(g.get_m(c), g.get_m_r(c), g.get_n_r(c), g.get_eta_rk_(c)) for c in picks]
+    labs = [g.get_memberships(c) for c in picks]
+    g.init_bisbm()  # recount from the labels
+    for (m, m_r, n_r, eta), c, lab in zip(before, picks, labs):
+        assert (g.get_m(c) == m).all() and (g.get_m_r(c) == m_r).all()
+        assert (g.get_n_r(c) == n_r).all() and (g.get_eta_rk_(c) == eta).all()
+        assert n_r.sum() == na + nb and m_r.sum() == 2 * E
+        assert (np.bincount(lab, minlength=ka + kb) == n_r).all()
+    ms, updates = g.last_sweep_timing()
+    assert updates == chains * (na + nb) and ms > 0
+    # chains are distinct (keyed by chain id) and reproducible: chain 3 re-run alone gives the same labels
+    assert (labs[0] != labs[1]).any()
+    solo = gpu_model(rowptr, col, na, nb, ka, kb, 1.0, labels, n_chains=1, rng="philox", seed=5, first_chain_id=7)
+    solo.shuffle_bisbm()
+    B.MetropolisHasting().anneal(solo, "constant", [1.0], na + nb, BIG)
+    assert (solo.get_memberships(0) == labs[1]).all()
