@@ -101,6 +101,18 @@ __device__ __forceinline__ double butterfly_sum_low32(double x) {
     return readlane(x, 31u);
 }
 
+// Two 32-leaf butterflies at once, one per half of the wave (leaves = lanes 0..31 and lanes 32..63): the five levels of
+// butterfly_sum_low32 without the read-out.  Afterwards every lane of row 1 (lanes 16..31) holds the sum of the lower
+// half and every lane of row 3 (lanes 48..63) the sum of the upper half; rows 0 and 2 hold garbage.
+__device__ __forceinline__ double butterfly_rows32(double x) {
+    x = x + dpp_f64<kDppXor1>(x);
+    x = x + dpp_f64<kDppXor2>(x);
+    x = x + dpp_f64<kDppHalfMirror>(x);
+    x = x + dpp_f64<kDppMirror>(x);
+    x = x + dpp_f64<kDppBcast15, 0xA>(x);
+    return x;
+}
+
 // inclusive prefix sum of int32 over the wave: Kogge-Stone inside rows (row_shr), then the row
 // totals are carried with row_bcast15 / row_bcast31
 __device__ __forceinline__ int wave_inclusive_scan(int x) {

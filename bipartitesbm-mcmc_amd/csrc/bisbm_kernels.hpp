@@ -66,6 +66,8 @@ struct SweepParams {
     // the workgroups keep their stepping waves on different SIMDs; NULL: wave `fixed_stepping_wave` (0 or 1) steps
     uint32_t* simd_claims;
     uint32_t fixed_stepping_wave;
+    // production kernel, K <= 32 and constant T: evaluate two consecutive steps per pass (0: one step per pass)
+    uint32_t pair_steps;
 };
 constexpr uint32_t kSimdClaims = 1u << 14;  // index: XCC_ID[3:0] | HW_ID se, sh, cu [15:8] | simd [5:4]
 

@@ -609,6 +609,10 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
 
     p.simd_claims = nullptr;
     p.fixed_stepping_wave = 0;
+    {
+        const char* single = getenv("BISBM_SINGLE_STEPS");  // =1: one step per pass in every variant (A/B checks, tests)
+        p.pair_steps = (single && single[0] == '1') ? 0u : 1u;
+    }
     if (fast) {
         const char* fixed = getenv("BISBM_FIXED_ROLES");  // =1: wave 0 always steps, =2: wave 1 (A/B checks, tests)
         if (fixed && fixed[0] == '2') p.fixed_stepping_wave = 1;

@@ -175,8 +175,11 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     // The stepping wave shares its SIMD with the feeder wave of another chain (four chains per CU): it is the
     // critical path, so it issues first whenever both have an instruction ready.
     if (is_main) __builtin_amdgcn_s_setprio(3);
-    int mrA = lane < ka ? mr_g[lane] : 0, nrA = lane < ka ? nr_g[lane] : 0;
-    int mrB = lane < kb ? mr_g[ka + lane] : 0, nrB = lane < kb ? nr_g[ka + lane] : 0;
+    // lane <-> block: m_r / n_r of block i sit in lane i; the K <= 32 variants keep a second copy in lane 32 + i, so that
+    // the upper half of the wave can run a step of its own (step_pair below)
+    const uint32_t lb = K32 ? (lane & 31u) : lane;
+    int mrA = lb < ka ? mr_g[lb] : 0, nrA = lb < ka ? nr_g[lb] : 0;
+    int mrB = lb < kb ? mr_g[ka + lb] : 0, nrB = lb < kb ? nr_g[ka + lb] : 0;
     __syncthreads();
     uint64_t sweeps_total = sc->sweeps_total;
 
@@ -199,6 +202,8 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     const bool never_direct = (p.rowptr[n] >> 1) + p.maxdeg <= (uint32_t)kQNmax;
     // the early-stop bookkeeping can only ever fire below T = 1, and only if steps_await can be reached within the call
     // (the counter starts at 0 and gains at most 1 per step) -- a scalar word, not a lane mask: one s_cmp to test
+    // two steps per pass (step_pair): K <= 32, constant T > 0; p.pair_steps == 0 switches it off (A/B runs, tests)
+    const bool pair_mode = (uint32_t)__builtin_amdgcn_readfirstlane((K32 && CT && T_const > 0. && p.pair_steps != 0) ? 1 : 0) != 0u;
     const uint32_t track_min =
         (uint32_t)__builtin_amdgcn_readfirstlane(((!CT || T_const < 1.) && p.steps_await <= p.duration) ? 1 : 0);
     // constants of the hot step (log_q closed form, accept filter)
@@ -242,8 +247,8 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
             auto mq_at = [&](uint32_t i_own, uint32_t j_oth) -> uint32_t {
                 return TB ? j_oth * S + i_own : i_own * S + j_oth;
             };
-            const double sign_tail = lane >= 8 ? 0. : ((lane < 2 || lane >= 6) ? -1. : 1.);
-            const double sign_q = lane >= 4 ? 0. : (lane < 2 ? -1. : 1.);
+            const double sign_tail = lb >= 8 ? 0. : ((lb < 2 || lb >= 6) ? -1. : 1.);
+            const double sign_q = lb >= 4 ? 0. : (lb < 2 ? -1. : 1.);
             const int eoff_l = (lane & 7u) < 6 ? 1 : ((lane & 1u) ? 2 : 0);       // eta_r+1, eta_s+1, eta_r, eta_s+2
             const int dq_l = (lane & 2u) ? ((lane & 1u) ? 1 : -1) : 0;            // n_r - 1, n_s + 1 in lanes 2,3 (mod 4)
             const int dsgn_l = dq_l;                                              // -deg, +deg in the same lanes
@@ -514,8 +519,8 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                             eta_wr(s * D + deg, (uint32_t)(eta_s + 1));
                             labels[v] = (uint8_t)s;
                         }
-                        mr_own += (lane == s_loc ? ideg : 0) - (lane == r_loc ? ideg : 0);
-                        nr_own += (lane == s_loc ? 1 : 0) - (lane == r_loc ? 1 : 0);
+                        mr_own += (lb == s_loc ? ideg : 0) - (lb == r_loc ? ideg : 0);
+                        nr_own += (lb == s_loc ? 1 : 0) - (lb == r_loc ? 1 : 0);
                         if (lane < k_oth) {  // k == 0: rewrites the same values
                             mq[a_rt] = m_rt - k;
                             mq[a_st] = m_st + k;
@@ -669,7 +674,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                         cum_l0 += dS;  // :500
                         acc_l0 += 1;
                     }
-                    const int dl = (int)min(lane ^ r_loc, 1u) - (int)min(lane ^ s_loc, 1u);  // +1 on lane s_loc, -1 on r_loc
+                    const int dl = (int)min(lb ^ r_loc, 1u) - (int)min(lb ^ s_loc, 1u);  // +1 on lane s_loc, -1 on r_loc
                     mr_own += __mul24(ideg, dl);
                     nr_own += dl;
                     if (lane < k_oth) {  // k == 0: rewrites the same values
@@ -680,8 +685,168 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     FSTAMP_STEP(8);
                     if constexpr (TM) new_minimum(q);
                 };
+                // ---- two steps per pass (K <= 32, constant T > 0, no early-stop bookkeeping) ----
+                // The hot step uses lanes 0..31 (one lane per block).  Here lanes 32..63 evaluate step q + 1 in the same
+                // instructions, against the same state, i.e. the state BEFORE step q.  That is step q + 1's true outcome
+                // unless step q moves its node (r -> s, r != s) AND touches something step q + 1 read:
+                //   rows r, s of m, m_r / n_r / eta of r, s       <=>  {r', s'} meets {r, s};
+                //   column t' of m (it feeds the inverse CDF)      <=>  k_q[t'] != 0 -- and then only rows r and s of the
+                //     column change, by -k and +k: the running sums move only for blocks in [min(r,s), max(r,s)), so a
+                //     target s' outside (min, max) is still the first block whose sum exceeds x.
+                // In those cases step q + 1 is evaluated again as the first step of the next pass; otherwise both
+                // steps are committed (their writes touch different rows).  The chain is the serial chain, bit for
+                // bit: the oracle knows nothing of this (orc_pair_probe counts how often the second step stands:
+                // ~80 % of the passes on the bench workload, 1.8 steps per pass).
+                const uint32_t half = lane >> 5;
+                auto step_pair = [&](uint32_t q) -> uint32_t {
+                    const int sel = (int)((q + half) << 2);
+                    FSTAMP_STEP(0);
+                    const uint32_t prop = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)prop_l);
+                    const uint32_t deg = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)deg_l);
+                    const uint32_t r_loc = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)rloc_l);
+                    const uint32_t t_loc = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)tloc_l);
+                    const uint32_t r_locA = readlane(rloc_l, q), r_locB = readlane(rloc_l, q + 1u);
+                    const int k = (int)hist8_cur[(q + half) * kHistStride + lb];
+                    const uint32_t a_rt = mq_at(r_loc, lb);
+                    const int32_t m_rt_raw = mq[a_rt];
+                    const int w_piv = mq[mq_at(lb, t_loc)];
+                    const int n_r_rA = readlane(nr_own, r_locA), n_r_rB = readlane(nr_own, r_locB);
+                    const int32_t kmask = (0 - k) >> 31;
+                    const int32_t m_rt = m_rt_raw & kmask;
+                    const uint32_t kk = (uint32_t)k;
+                    const double L1 = tab_at(tab.lg, (uint32_t)(m_rt + 1));
+                    const double L3 = tab_at(tab.lg, (uint32_t)(m_rt + 1) - kk);
+                    __asm__ volatile("" ::: "memory");
+                    FSTAMP_STEP(1);
+                    // inverse CDF per half (:627-628): the scan does not cross lane 31 -> 32
+                    const int scan = wave_inclusive_scan32(w_piv);
+                    const unsigned long long hit = __builtin_amdgcn_ballot_w64((uint32_t)scan > prop);
+                    uint32_t fhA, fhB;
+                    __asm__("s_ff1_i32_b32 %0, %1" : "=s"(fhA) : "s"((uint32_t)hit));
+                    __asm__("s_ff1_i32_b32 %0, %1" : "=s"(fhB) : "s"((uint32_t)(hit >> 32)));
+                    const uint32_t s_locA = min(fhA, last_own), s_locB = min(fhB, last_own);
+                    const bool selfA = s_locA == r_locA, selfB = s_locB == r_locB;
+                    FSTAMP_STEP(2);
+                    if (selfA && selfB) {  // both r == s: nothing changes (:109-112)
+                        const uint32_t okc = (n_r_rA != 1 ? 1u : 0u) + (n_r_rB != 1 ? 1u : 0u);
+                        if (lane == 0) acc_l0 += okc;
+                        return 2u;
+                    }
+                    const uint32_t s_loc = half ? s_locB : s_locA;
+                    const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
+                    const uint32_t a_st = mq_at(s_loc, lb);
+                    const int32_t m_st_raw = mq[a_st];
+                    const uint32_t e_idx = (own_base + idx_l) * D + deg;
+                    const int ee = (int)eta_rd(e_idx);
+                    const int mm = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), mr_own);
+                    const int nn = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), nr_own);
+                    const int32_t m_st = m_st_raw & kmask;
+                    const int ideg = (int)deg;
+                    const int qn = mm + __mul24(ideg, dsgn_l);        // m0r, m0s, m0r - deg, m0s + deg
+                    const uint32_t tail_idx = (uint32_t)((qn ^ ((qn ^ ee) & eta_mask_l)) + toff_l);
+                    const int qk = nn + dq_l;
+                    const double tail_lg = tab_at(tab.lg, tail_idx);
+                    const double logn = tab_at(tab.logtab, (uint32_t)qn);
+                    const double L2 = tab_at(tab.lg, (uint32_t)(m_st + 1));
+                    const double L4 = tab_at(tab.lg, (uint32_t)(m_st + 1) + kk);
+                    FSTAMP_STEP(3);
+                    const double a0 = k * (m_st + eps) * inv_oth;
+                    const double a1 = k * (m_rt - k + eps) * inv_oth;
+                    const double accu0 = butterfly_rows32(a0);  // lanes 16..31: step q, lanes 48..63: step q + 1
+                    const double accu1 = butterfly_rows32(a1);
+                    FSTAMP_STEP(4);
+                    double lq;
+                    {
+                        const int qk2 = qk < qn ? qk : qn;
+                        const double nd = (double)qn, kd = (double)qk2;
+                        const double k2 = kd * kd;
+                        const bool direct = qn > kQNmax && k2 > c_576 * nd;
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!direct) == 0, 1)) {
+                            double sq, rr;
+                            sqrt_rsqrt(nd, sq, rr);
+                            lq = log_q_closed(kd, sq, rr, logn, lqc);
+                        } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= ldexp(nd, 6))) == 0) {
+                            double sq, rr;
+                            sqrt_rsqrt(nd, sq, rr);
+                            const double lq_mid = log_q_mid(kd, sq, rr, logn, lqc);
+                            const double lq_far = log_q_closed(kd, sq, rr, logn, lqc);
+                            lq = direct ? lq_far : lq_mid;
+                        } else {
+                            lq = log_q<true>(tab, qn, qk, logn);
+                        }
+                    }
+                    FSTAMP_STEP(5);
+                    double d = (L1 + L2) - (L3 + L4);
+                    d = d + tail_lg * sign_tail;
+                    d = d + lq * sign_q;
+                    const double dS = butterfly_rows32(d);
+                    FSTAMP_STEP(6);
+                    // accept (:47-61) in the lanes that hold the sums; bit 31 is step q's verdict, bit 63 step q + 1's
+                    const double u_acc = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(ud_acc)),
+                                                          __builtin_amdgcn_ds_bpermute(sel, __double2loint(ud_acc)));
+                    const double z = -dS * invT_const;
+                    const double est = accu1 * exp2_filter(z * c_l2e);
+                    const double lhs = u_acc * accu0;
+                    unsigned long long b_acc = __builtin_amdgcn_ballot_w64(lhs < est);
+                    const unsigned long long b_far = __builtin_amdgcn_ballot_w64(fabs(lhs - est) > c_tol * est);
+                    constexpr unsigned long long kVerdicts = (1ull << 31) | (1ull << 63);
+                    if (__builtin_expect((~b_far & kVerdicts) != 0, 0)) b_acc = __builtin_amdgcn_ballot_w64(lhs < accu1 * exp(z));
+                    FSTAMP_STEP(7);
+                    const bool okA = n_r_rA != 1 && (selfA || ((b_acc >> 31) & 1ull));  // (:467-471: veto after the draw)
+                    const bool chA = okA && !selfA;
+                    bool stands = true;  // does step q + 1's evaluation stand?
+                    if (chA) {
+                        const uint32_t lo = min(r_locA, s_locA), hi = max(r_locA, s_locA);
+                        const bool rows = r_locB == r_locA || r_locB == s_locA || s_locB == r_locA || s_locB == s_locA;
+                        const bool col = s_locB > lo && s_locB < hi && readlane((uint32_t)k, readlane(tloc_l, q + 1u)) != 0u;
+                        stands = !(rows || col);
+                    }
+                    const bool okB = stands && n_r_rB != 1 && (selfB || ((b_acc >> 63) & 1ull));
+                    const bool chB = okB && !selfB;
+                    const uint32_t n_ok = (okA ? 1u : 0u) + (okB ? 1u : 0u);
+                    if (chA || chB) {
+                        // ---- apply_mcmc_moves, blockmodel.cc:461-503, for the step(s) that move ----
+                        const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)v_l);
+                        const bool mine = half ? chB : chA;
+                        wfence();
+                        if (mine) {
+                            if (lb < k_oth) {  // k == 0: rewrites the same values
+                                mq[a_rt] = m_rt_raw - k;
+                                mq[a_st] = m_st_raw + k;
+                            }
+                            if ((lb & ~1u) == 4u) eta_wr(e_idx, (uint32_t)(ee + ((int)(lb & 1u) * 2 - 1)));  // lane 4: eta_r - 1, lane 5: eta_s + 1
+                            if (lb == 0u) labels[v] = (uint8_t)(own_base + s_loc);
+                        }
+                        const int dlA = (int)min(lb ^ r_locA, 1u) - (int)min(lb ^ s_locA, 1u);  // +1 on lane s, -1 on lane r
+                        const int dlB = (int)min(lb ^ r_locB, 1u) - (int)min(lb ^ s_locB, 1u);
+                        const int oneA = chA ? 1 : 0, oneB = chB ? 1 : 0;
+                        const int degA = chA ? (int)readlane(deg_l, q) : 0, degB = chB ? (int)readlane(deg_l, q + 1u) : 0;
+                        mr_own += __mul24(degA, dlA) + __mul24(degB, dlB);
+                        nr_own += __mul24(oneA, dlA) + __mul24(oneB, dlB);
+                        if (chA && lane == 0) cum_l0 += readlane(dS, 31u);  // :500, in step order
+                        if (chB && lane == 0) cum_l0 += readlane(dS, 63u);
+                        wfence();
+                    }
+                    if (lane == 0) acc_l0 += n_ok;
+                    FSTAMP_STEP(8);
+                    return stands ? 2u : 1u;
+                };
+
+                constexpr bool kPairs = K32 && CT;
                 if (track_min != 0u) {
                     for (uint32_t q = 0; q < cnt; ++q) step(std::true_type{}, q);
+                } else if (kPairs && pair_mode) {
+                    // steps that need the general path (bit 31 of prop_l) go one at a time
+                    const unsigned long long gen_mask = __builtin_amdgcn_ballot_w64((int32_t)prop_l < 0);
+                    uint32_t q = 0;
+                    while (q < cnt) {
+                        if (q + 1u < cnt && ((gen_mask >> q) & 3ull) == 0ull) {
+                            q += step_pair(q);
+                        } else {
+                            step(std::false_type{}, q);
+                            q += 1u;
+                        }
+                    }
                 } else {
                     for (uint32_t q = 0; q < cnt; ++q) step(std::false_type{}, q);
                 }

@@ -1090,6 +1090,92 @@ static int step_philox(orc_model *m, size_t v, double temperature, uint64_t gste
     return 0;
 }
 
+/* Diagnostic ("two steps per wave"): runs `sweeps` Philox-mode sweeps at constant T exactly as
+ * orc_anneal does and, along the way, counts how often step q+1 of a 64-node chunk could have been evaluated against
+ * the state BEFORE step q without changing its outcome: step q not applied (rejected, vetoed or r == s), or applied
+ * with {r,s} disjoint from {r',s'} and k_q[t'] == 0 (t' = block of step q+1's pivot neighbour: column t' of m feeds its
+ * proposal).  out: {steps, pair evaluations, pairs whose second step stood, first steps applied, conflicts by row,
+ * conflicts by column only}. */
+void orc_pair_probe(orc_model *m, uint64_t sweeps, double temperature, uint64_t out[6]) {
+    size_t n = m->n;
+    int *kv_a = (int *)malloc(sizeof(int) * m->K);
+    memset(out, 0, sizeof(uint64_t) * 6);
+    for (uint64_t sw = 0; sw < sweeps; ++sw) {
+        uint32_t keys[2][4];
+        phx_draw(m->phx_seed, m->phx_chain, PHX_SWEEP_KEY, 2 * m->sweeps_total, keys[0]);
+        phx_draw(m->phx_seed, m->phx_chain, PHX_SWEEP_KEY, 2 * m->sweeps_total + 1, keys[1]);
+        for (int ph = 0; ph < 2; ++ph) {
+            size_t n_own = ph ? m->nb : m->na, base = ph ? m->na : 0;
+            for (size_t c0 = 0; c0 < n_own; c0 += 64) {
+                size_t cnt = n_own - c0 < 64 ? n_own - c0 : 64;
+                size_t q = 0;
+                while (q < cnt) {
+                    size_t vi = base + c0 + q;
+                    size_t v = base + tiled_perm(keys[ph], (uint32_t)n_own, (uint32_t)(c0 + q));
+                    uint64_t gs = m->sweeps_total * n + vi;
+                    size_t r = m->labels[v];
+                    int have_b = q + 1 < cnt;
+                    size_t rb = 0, sb = 0, tb = 0;
+                    int b_uses_column = 0;
+                    if (have_b) { /* step q+1's proposal on the state before step q */
+                        size_t vb = base + tiled_perm(keys[ph], (uint32_t)n_own, (uint32_t)(c0 + q + 1));
+                        uint32_t A[4], B[4];
+                        phx_draw(m->phx_seed, m->phx_chain, PHX_STEP_A, gs + 1, A);
+                        phx_draw(m->phx_seed, m->phx_chain, PHX_STEP_B, gs + 1, B);
+                        rb = m->labels[vb];
+                        sb = propose_philox(m, vb, u53(A[0], A[1]), u53(A[2], A[3]), u53(B[0], B[1]));
+                        size_t d = (size_t)m->deg[vb];
+                        if (d) {
+                            size_t which = (size_t)(u53(A[0], A[1]) * (double)d);
+                            if (which >= d) which = d - 1;
+                            tb = m->labels[m->col[m->rowptr[vb] + which]];
+                            b_uses_column = 1;
+                        }
+                    }
+                    compute_kv(m, v);
+                    memcpy(kv_a, m->kv, sizeof(int) * m->K);
+                    int ok = step_philox(m, v, temperature, gs);
+                    size_t s = m->labels[v];
+                    int changed = ok && s != r;
+                    out[0]++;
+                    out[3] += (uint64_t)changed;
+                    if (!have_b) {
+                        q += 1;
+                        continue;
+                    }
+                    out[1]++;
+                    int row = changed && (rb == r || rb == s || sb == r || sb == s);
+                    /* column t' of m changes where k_q[t'] != 0, but only rows r and s of it: the running sums of the
+                     * inverse CDF move only for blocks in [min(r,s), max(r,s)), so a target outside that span stands */
+                    size_t lo_rs = r < s ? r : s, hi_rs = r < s ? s : r;
+                    int col = changed && b_uses_column && kv_a[tb] != 0 && sb > lo_rs && sb < hi_rs;
+                    if (row)
+                        out[4]++;
+                    else if (col)
+                        out[5]++;
+                    if (row || col) {
+                        q += 1;
+                    } else {
+                        size_t vb = base + tiled_perm(keys[ph], (uint32_t)n_own, (uint32_t)(c0 + q + 1));
+                        { /* the claim itself: the proposal evaluated after step q is the one evaluated before it */
+                            uint32_t A[4], B[4];
+                            phx_draw(m->phx_seed, m->phx_chain, PHX_STEP_A, gs + 1, A);
+                            phx_draw(m->phx_seed, m->phx_chain, PHX_STEP_B, gs + 1, B);
+                            if (propose_philox(m, vb, u53(A[0], A[1]), u53(A[2], A[3]), u53(B[0], B[1])) != sb) abort();
+                        }
+                        step_philox(m, vb, temperature, gs + 1);
+                        out[0]++;
+                        out[2]++;
+                        q += 2;
+                    }
+                }
+            }
+        }
+        m->sweeps_total++;
+    }
+    free(kv_a);
+}
+
 /* metropolis_hasting.cc:64-101 */
 double orc_anneal(orc_model *m, int schedule, float kw0, float kw1, uint64_t duration,
                   uint64_t steps_await) {
