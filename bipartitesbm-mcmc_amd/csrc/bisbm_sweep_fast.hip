@@ -259,6 +259,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
             TiledOrder order;
             order.init(phx_draw(p.seed, chain_gid, PHX_SWEEP_KEY, 2 * sweeps_total + (TB ? 1 : 0)), n_own);
             const uint32_t n_chunks = (n_own + kWave - 1) / kWave;
+            const unsigned long long lanes_koth = __builtin_amdgcn_ballot_w64(lb < k_oth);  // both halves in the K <= 32 variants
             const uint32_t node_other0 = TB ? 0u : na;  // some node of the opposite type: what idle slots of the walk load
 
             // ---- feeder wave: everything of chunk c that does not depend on the chain's block state ----
@@ -698,19 +699,30 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                 // bit: the oracle knows nothing of this (orc_pair_probe counts how often the second step stands:
                 // ~80 % of the passes on the bench workload, 1.8 steps per pass).
                 const uint32_t half = lane >> 5;
-                auto step_pair = [&](uint32_t q) -> uint32_t {
-                    const int sel = (int)((q + half) << 2);
+                // per-step inputs of the pair pass: degree, own block and pivot block in one word (one cross-lane move)
+                const uint32_t pack_l = (deg_l & 255u) | ((rloc_l & 63u) << 8) | (tloc_l << 16);
+                // q: first step of the pass; pairable: 1 = lanes 32..63 evaluate step q + 1, 0 = nothing to pair with
+                // (last step of the chunk, or a step that needs the general path next): both halves evaluate step q
+                auto step_pair = [&](uint32_t q, uint32_t pairable) -> uint32_t {
+                    const uint32_t qB = q + pairable;
+                    const uint32_t qs = half ? qB : q;
+                    const int sel = (int)(qs << 2);
                     FSTAMP_STEP(0);
+                    const uint32_t pack = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)pack_l);
                     const uint32_t prop = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)prop_l);
-                    const uint32_t deg = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)deg_l);
-                    const uint32_t r_loc = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)rloc_l);
-                    const uint32_t t_loc = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)tloc_l);
-                    const uint32_t r_locA = readlane(rloc_l, q), r_locB = readlane(rloc_l, q + 1u);
-                    const int k = (int)hist8_cur[(q + half) * kHistStride + lb];
+                    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)v_l);
+                    const double u_acc = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(ud_acc)),
+                                                          __builtin_amdgcn_ds_bpermute(sel, __double2loint(ud_acc)));
+                    const uint32_t packA = readlane(pack_l, q), packB = readlane(pack_l, qB);
+                    const uint32_t r_locA = (packA >> 8) & 63u, r_locB = (packB >> 8) & 63u;
+                    const uint32_t degA = packA & 255u, degB = packB & 255u, t_locB = packB >> 16;
+                    const uint32_t deg = pack & 255u, r_loc = (pack >> 8) & 63u, t_loc = pack >> 16;
+                    const int k = (int)hist8_cur[qs * kHistStride + lb];
                     const uint32_t a_rt = mq_at(r_loc, lb);
                     const int32_t m_rt_raw = mq[a_rt];
                     const int w_piv = mq[mq_at(lb, t_loc)];
-                    const int n_r_rA = readlane(nr_own, r_locA), n_r_rB = readlane(nr_own, r_locB);
+                    const uint32_t liveA = readlane(nr_own, r_locA) != 1 ? 1u : 0u;  // (:467-471: a block is never emptied)
+                    const uint32_t liveB = readlane(nr_own, r_locB) != 1 ? pairable : 0u;
                     const int32_t kmask = (0 - k) >> 31;
                     const int32_t m_rt = m_rt_raw & kmask;
                     const uint32_t kk = (uint32_t)k;
@@ -725,13 +737,19 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     __asm__("s_ff1_i32_b32 %0, %1" : "=s"(fhA) : "s"((uint32_t)hit));
                     __asm__("s_ff1_i32_b32 %0, %1" : "=s"(fhB) : "s"((uint32_t)(hit >> 32)));
                     const uint32_t s_locA = min(fhA, last_own), s_locB = min(fhB, last_own);
-                    const bool selfA = s_locA == r_locA, selfB = s_locB == r_locB;
+                    const uint32_t selfA = s_locA == r_locA ? 1u : 0u, selfB = s_locB == r_locB ? 1u : 0u;
                     FSTAMP_STEP(2);
-                    if (selfA && selfB) {  // both r == s: nothing changes (:109-112)
-                        const uint32_t okc = (n_r_rA != 1 ? 1u : 0u) + (n_r_rB != 1 ? 1u : 0u);
-                        if (lane == 0) acc_l0 += okc;
-                        return 2u;
+                    if ((selfA & selfB) != 0u) {  // both r == s: nothing changes (:109-112)
+                        acc_l0 += (unsigned long long)(liveA + liveB);
+                        return 1u + pairable;
                     }
+                    // Would step q, if it moves its node, touch what step q + 1 read?  (block sets as bit masks)
+                    const uint32_t setA = (1u << r_locA) | (1u << s_locA), setB = (1u << r_locB) | (1u << s_locB);
+                    const uint32_t lo = min(r_locA, s_locA), hi = max(r_locA, s_locA);
+                    const uint32_t between = ((1u << hi) - 1u) & ~((2u << lo) - 1u);  // blocks strictly between r and s
+                    const uint32_t kAtB = readlane(kk, t_locB);                        // (lanes 0..31 hold k_q[.])
+                    const uint32_t clash = ((setA & setB) != 0u || (((between >> s_locB) & 1u) != 0u && kAtB != 0u)) ? 1u : 0u;
+
                     const uint32_t s_loc = half ? s_locB : s_locA;
                     const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
                     const uint32_t a_st = mq_at(s_loc, lb);
@@ -780,10 +798,9 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     d = d + tail_lg * sign_tail;
                     d = d + lq * sign_q;
                     const double dS = butterfly_rows32(d);
+                    const double dS_A = readlane(dS, 31u), dS_B = readlane(dS, 63u);  // (for the running sum, :500)
                     FSTAMP_STEP(6);
                     // accept (:47-61) in the lanes that hold the sums; bit 31 is step q's verdict, bit 63 step q + 1's
-                    const double u_acc = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(ud_acc)),
-                                                          __builtin_amdgcn_ds_bpermute(sel, __double2loint(ud_acc)));
                     const double z = -dS * invT_const;
                     const double est = accu1 * exp2_filter(z * c_l2e);
                     const double lhs = u_acc * accu0;
@@ -792,44 +809,34 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     constexpr unsigned long long kVerdicts = (1ull << 31) | (1ull << 63);
                     if (__builtin_expect((~b_far & kVerdicts) != 0, 0)) b_acc = __builtin_amdgcn_ballot_w64(lhs < accu1 * exp(z));
                     FSTAMP_STEP(7);
-                    const bool okA = n_r_rA != 1 && (selfA || ((b_acc >> 31) & 1ull));  // (:467-471: veto after the draw)
-                    const bool chA = okA && !selfA;
-                    bool stands = true;  // does step q + 1's evaluation stand?
-                    if (chA) {
-                        const uint32_t lo = min(r_locA, s_locA), hi = max(r_locA, s_locA);
-                        const bool rows = r_locB == r_locA || r_locB == s_locA || s_locB == r_locA || s_locB == s_locA;
-                        const bool col = s_locB > lo && s_locB < hi && readlane((uint32_t)k, readlane(tloc_l, q + 1u)) != 0u;
-                        stands = !(rows || col);
-                    }
-                    const bool okB = stands && n_r_rB != 1 && (selfB || ((b_acc >> 63) & 1ull));
-                    const bool chB = okB && !selfB;
-                    const uint32_t n_ok = (okA ? 1u : 0u) + (okB ? 1u : 0u);
-                    if (chA || chB) {
-                        // ---- apply_mcmc_moves, blockmodel.cc:461-503, for the step(s) that move ----
-                        const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)v_l);
-                        const bool mine = half ? chB : chA;
+                    const uint32_t yesA = (uint32_t)(b_acc >> 31) & 1u, yesB = (uint32_t)(b_acc >> 63) & 1u;
+                    const uint32_t chA = liveA & yesA & (selfA ^ 1u);            // step q moves its node
+                    const uint32_t okA = liveA & (selfA | yesA);                 // ... counts as accepted
+                    const uint32_t stands = pairable & ((chA & clash) ^ 1u);     // step q + 1's evaluation stands
+                    const uint32_t chB = stands & liveB & yesB & (selfB ^ 1u);
+                    const uint32_t okB = stands & liveB & (selfB | yesB);
+                    acc_l0 += (unsigned long long)(okA + okB);
+                    if ((chA | chB) != 0u) {
+                        // ---- apply_mcmc_moves, blockmodel.cc:461-503, for the step(s) that move: their rows differ ----
+                        const unsigned long long movers = (chA ? 0x00000000ffffffffull : 0ull) | (chB ? 0xffffffff00000000ull : 0ull);
                         wfence();
-                        if (mine) {
-                            if (lb < k_oth) {  // k == 0: rewrites the same values
-                                mq[a_rt] = m_rt_raw - k;
-                                mq[a_st] = m_st_raw + k;
-                            }
-                            if ((lb & ~1u) == 4u) eta_wr(e_idx, (uint32_t)(ee + ((int)(lb & 1u) * 2 - 1)));  // lane 4: eta_r - 1, lane 5: eta_s + 1
-                            if (lb == 0u) labels[v] = (uint8_t)(own_base + s_loc);
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & lanes_koth)) {  // k == 0: rewrites the same values
+                            mq[a_rt] = m_rt_raw - k;
+                            mq[a_st] = m_st_raw + k;
                         }
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000003000000030ull))  // lanes 4, 5: eta_r - 1, eta_s + 1
+                            eta_wr(e_idx, (uint32_t)(ee + ((int)(lb & 1u) * 2 - 1)));
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000000100000001ull)) labels[v] = (uint8_t)(own_base + s_loc);
                         const int dlA = (int)min(lb ^ r_locA, 1u) - (int)min(lb ^ s_locA, 1u);  // +1 on lane s, -1 on lane r
                         const int dlB = (int)min(lb ^ r_locB, 1u) - (int)min(lb ^ s_locB, 1u);
-                        const int oneA = chA ? 1 : 0, oneB = chB ? 1 : 0;
-                        const int degA = chA ? (int)readlane(deg_l, q) : 0, degB = chB ? (int)readlane(deg_l, q + 1u) : 0;
-                        mr_own += __mul24(degA, dlA) + __mul24(degB, dlB);
-                        nr_own += __mul24(oneA, dlA) + __mul24(oneB, dlB);
-                        if (chA && lane == 0) cum_l0 += readlane(dS, 31u);  // :500, in step order
-                        if (chB && lane == 0) cum_l0 += readlane(dS, 63u);
+                        mr_own += __mul24((int)(chA ? degA : 0u), dlA) + __mul24((int)(chB ? degB : 0u), dlB);
+                        nr_own += __mul24((int)chA, dlA) + __mul24((int)chB, dlB);
+                        cum_l0 += chA ? dS_A : 0.;  // :500, in step order (x + 0.0 is x: the running sum is never -0.0)
+                        cum_l0 += chB ? dS_B : 0.;
                         wfence();
                     }
-                    if (lane == 0) acc_l0 += n_ok;
                     FSTAMP_STEP(8);
-                    return stands ? 2u : 1u;
+                    return 1u + stands;
                 };
 
                 constexpr bool kPairs = K32 && CT;
@@ -840,11 +847,12 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     const unsigned long long gen_mask = __builtin_amdgcn_ballot_w64((int32_t)prop_l < 0);
                     uint32_t q = 0;
                     while (q < cnt) {
-                        if (q + 1u < cnt && ((gen_mask >> q) & 3ull) == 0ull) {
-                            q += step_pair(q);
-                        } else {
-                            step(std::false_type{}, q);
+                        const uint32_t two = (uint32_t)(gen_mask >> q) & 3u;
+                        if (__builtin_expect((two & 1u) != 0u, 0)) {
+                            step_general(q, T_const);
                             q += 1u;
+                        } else {
+                            q += step_pair(q, q + 1u < cnt ? (two >> 1) ^ 1u : 0u);
                         }
                     }
                 } else {

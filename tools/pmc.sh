@@ -8,7 +8,7 @@ mkdir -p $OUT; export TMPDIR=/tmp
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc$i -o pmc -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline $BENCH_ARGS > $OUT/pmc$i.json 2> $OUT/pmc$i.err || echo "pass $i ($grp) failed"
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc$i -o pmc -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras $BENCH_ARGS > $OUT/pmc$i.json 2> $OUT/pmc$i.err || echo "pass $i ($grp) failed"
 done
 python3 tools/summarize_pmc.py $OUT/pmc_counters.csv sweep_fast $OUT/pmc[0-9]* > /dev/null
 python3 -c "import csv,sys; [print(r[0], r[2], r[3]) for r in csv.reader(open(sys.argv[1]))]" $OUT/pmc_counters.csv

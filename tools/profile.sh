@@ -6,7 +6,7 @@ set -e
 TAG=${1:-run}; shift || true
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT; export TMPDIR=/tmp
-ARGS="--no-cpu-baseline $@"
+ARGS="--no-cpu-baseline --no-extras $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --steps 6 --warmup 2 $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
 find $OUT/kt -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 i=0
