@@ -87,6 +87,20 @@ struct __attribute__((packed, aligned(4))) Id4 {  // four consecutive column ids
     uint32_t x, y, z, w;
 };
 
+// min(x, 1) on the scalar unit: x != 0 as a 0 / 1 word.  Written as the instruction itself: the compiler turns the
+// C expression into a compare whose boolean it then materialises through the vector unit (v_cndmask +
+// v_readfirstlane, ~30 cycles of latency each on a lone wave).
+__device__ __forceinline__ uint32_t sflag(uint32_t x) {
+    uint32_t r;
+    __asm__("s_min_u32 %0, %1, 1" : "=s"(r) : "s"(x) : "scc");
+    return r;
+}
+__device__ __forceinline__ uint32_t smin(uint32_t x, uint32_t y) {
+    uint32_t r;
+    __asm__("s_min_u32 %0, %1, %2" : "=s"(r) : "s"(x), "s"(y) : "scc");
+    return r;
+}
+
 constexpr uint32_t kHistStride = 68;  // bytes per k_v row: 64 counters + pad (17 dwords: odd, conflict-free)
 constexpr uint32_t kHandWords = 5;    // v, row begin, degree, own label, pivot label
 constexpr uint32_t kRowCap = 255;     // longest row the feeder walks (a k_v counter is a byte); longer rows: per-step side path
@@ -699,13 +713,15 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                 // bit: the oracle knows nothing of this (orc_pair_probe counts how often the second step stands:
                 // ~80 % of the passes on the bench workload, 1.8 steps per pass).
                 const uint32_t half = lane >> 5;
+                uint32_t acc_chunk = 0;  // accepted steps of the chunk's pair passes (a scalar word; added to acc_l0 per chunk)
                 // per-step inputs of the pair pass: degree, own block and pivot block in one word (one cross-lane move)
                 const uint32_t pack_l = (deg_l & 255u) | ((rloc_l & 63u) << 8) | (tloc_l << 16);
                 // q: first step of the pass; pairable: 1 = lanes 32..63 evaluate step q + 1, 0 = nothing to pair with
                 // (last step of the chunk, or a step that needs the general path next): both halves evaluate step q
                 auto step_pair = [&](uint32_t q, uint32_t pairable) -> uint32_t {
                     const uint32_t qB = q + pairable;
-                    const uint32_t qs = half ? qB : q;
+                    const uint32_t qs = q + (half & (0u - pairable));  // (flags are 0 / 1 words and selections arithmetic: a bool
+                                                                         // select of uniform values goes through the vector unit and back)
                     const int sel = (int)(qs << 2);
                     FSTAMP_STEP(0);
                     const uint32_t pack = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)pack_l);
@@ -721,8 +737,8 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     const uint32_t a_rt = mq_at(r_loc, lb);
                     const int32_t m_rt_raw = mq[a_rt];
                     const int w_piv = mq[mq_at(lb, t_loc)];
-                    const uint32_t liveA = readlane(nr_own, r_locA) != 1 ? 1u : 0u;  // (:467-471: a block is never emptied)
-                    const uint32_t liveB = readlane(nr_own, r_locB) != 1 ? pairable : 0u;
+                    const uint32_t liveA = sflag((uint32_t)readlane(nr_own, r_locA) ^ 1u);  // n_r != 1 (:467-471: a block is never emptied)
+                    const uint32_t liveB = smin((uint32_t)readlane(nr_own, r_locB) ^ 1u, pairable);
                     const int32_t kmask = (0 - k) >> 31;
                     const int32_t m_rt = m_rt_raw & kmask;
                     const uint32_t kk = (uint32_t)k;
@@ -737,10 +753,10 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     __asm__("s_ff1_i32_b32 %0, %1" : "=s"(fhA) : "s"((uint32_t)hit));
                     __asm__("s_ff1_i32_b32 %0, %1" : "=s"(fhB) : "s"((uint32_t)(hit >> 32)));
                     const uint32_t s_locA = min(fhA, last_own), s_locB = min(fhB, last_own);
-                    const uint32_t selfA = s_locA == r_locA ? 1u : 0u, selfB = s_locB == r_locB ? 1u : 0u;
+                    const uint32_t selfA = 1u - sflag(s_locA ^ r_locA), selfB = 1u - sflag(s_locB ^ r_locB);
                     FSTAMP_STEP(2);
                     if ((selfA & selfB) != 0u) {  // both r == s: nothing changes (:109-112)
-                        acc_l0 += (unsigned long long)(liveA + liveB);
+                        acc_chunk += liveA + liveB;
                         return 1u + pairable;
                     }
                     // Would step q, if it moves its node, touch what step q + 1 read?  (block sets as bit masks)
@@ -748,9 +764,13 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     const uint32_t lo = min(r_locA, s_locA), hi = max(r_locA, s_locA);
                     const uint32_t between = ((1u << hi) - 1u) & ~((2u << lo) - 1u);  // blocks strictly between r and s
                     const uint32_t kAtB = readlane(kk, t_locB);                        // (lanes 0..31 hold k_q[.])
-                    const uint32_t clash = ((setA & setB) != 0u || (((between >> s_locB) & 1u) != 0u && kAtB != 0u)) ? 1u : 0u;
+                    const uint32_t clash = sflag(setA & setB) | (((between >> s_locB) & 1u) & sflag(kAtB));
+                    // what the verdicts will be combined with, in one word (the scalar file is full): bit 0 step q can
+                    // move, bit 1 step q is an accepted r == s, bits 2, 3 the same for step q + 1, bit 4 the clash
+                    const uint32_t flags = (liveA & (selfA ^ 1u)) | ((liveA & selfA) << 1) | ((liveB & (selfB ^ 1u)) << 2) |
+                                           ((liveB & selfB) << 3) | (clash << 4);
 
-                    const uint32_t s_loc = half ? s_locB : s_locA;
+                    const uint32_t s_loc = (uint32_t)((int)s_locA + __mul24((int)half, (int)s_locB - (int)s_locA));
                     const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
                     const uint32_t a_st = mq_at(s_loc, lb);
                     const int32_t m_st_raw = mq[a_st];
@@ -798,7 +818,6 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     d = d + tail_lg * sign_tail;
                     d = d + lq * sign_q;
                     const double dS = butterfly_rows32(d);
-                    const double dS_A = readlane(dS, 31u), dS_B = readlane(dS, 63u);  // (for the running sum, :500)
                     FSTAMP_STEP(6);
                     // accept (:47-61) in the lanes that hold the sums; bit 31 is step q's verdict, bit 63 step q + 1's
                     const double z = -dS * invT_const;
@@ -806,19 +825,22 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     const double lhs = u_acc * accu0;
                     unsigned long long b_acc = __builtin_amdgcn_ballot_w64(lhs < est);
                     const unsigned long long b_far = __builtin_amdgcn_ballot_w64(fabs(lhs - est) > c_tol * est);
-                    constexpr unsigned long long kVerdicts = (1ull << 31) | (1ull << 63);
-                    if (__builtin_expect((~b_far & kVerdicts) != 0, 0)) b_acc = __builtin_amdgcn_ballot_w64(lhs < accu1 * exp(z));
+                    if (__builtin_expect((((uint32_t)b_far & (uint32_t)(b_far >> 32)) >> 31) == 0u, 0))  // a verdict too close to call
+                        b_acc = __builtin_amdgcn_ballot_w64(lhs < accu1 * exp(z));
                     FSTAMP_STEP(7);
                     const uint32_t yesA = (uint32_t)(b_acc >> 31) & 1u, yesB = (uint32_t)(b_acc >> 63) & 1u;
-                    const uint32_t chA = liveA & yesA & (selfA ^ 1u);            // step q moves its node
-                    const uint32_t okA = liveA & (selfA | yesA);                 // ... counts as accepted
-                    const uint32_t stands = pairable & ((chA & clash) ^ 1u);     // step q + 1's evaluation stands
-                    const uint32_t chB = stands & liveB & yesB & (selfB ^ 1u);
-                    const uint32_t okB = stands & liveB & (selfB | yesB);
-                    acc_l0 += (unsigned long long)(okA + okB);
+                    const uint32_t chA = flags & yesA;                                  // step q moves its node
+                    const uint32_t okA = chA | ((flags >> 1) & 1u);                     // ... counts as accepted
+                    const uint32_t stands = pairable & ((chA & (flags >> 4)) ^ 1u);     // step q + 1's evaluation stands
+                    const uint32_t chB = stands & (flags >> 2) & yesB;
+                    const uint32_t okB = chB | (stands & (flags >> 3) & 1u);
+                    acc_chunk += okA + okB;
                     if ((chA | chB) != 0u) {
                         // ---- apply_mcmc_moves, blockmodel.cc:461-503, for the step(s) that move: their rows differ ----
-                        const unsigned long long movers = (chA ? 0x00000000ffffffffull : 0ull) | (chB ? 0xffffffff00000000ull : 0ull);
+                        const uint32_t mA = 0u - chA, mB = 0u - chB;  // all ones / zero
+                        const int dS_A_lo = __builtin_amdgcn_readlane(__double2loint(dS), 31), dS_A_hi = __builtin_amdgcn_readlane(__double2hiint(dS), 31);
+                        const int dS_B_lo = __builtin_amdgcn_readlane(__double2loint(dS), 63), dS_B_hi = __builtin_amdgcn_readlane(__double2hiint(dS), 63);
+                        const unsigned long long movers = ((unsigned long long)mB << 32) | mA;
                         wfence();
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & lanes_koth)) {  // k == 0: rewrites the same values
                             mq[a_rt] = m_rt_raw - k;
@@ -829,10 +851,11 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000000100000001ull)) labels[v] = (uint8_t)(own_base + s_loc);
                         const int dlA = (int)min(lb ^ r_locA, 1u) - (int)min(lb ^ s_locA, 1u);  // +1 on lane s, -1 on lane r
                         const int dlB = (int)min(lb ^ r_locB, 1u) - (int)min(lb ^ s_locB, 1u);
-                        mr_own += __mul24((int)(chA ? degA : 0u), dlA) + __mul24((int)(chB ? degB : 0u), dlB);
+                        mr_own += __mul24((int)(degA & mA), dlA) + __mul24((int)(degB & mB), dlB);
                         nr_own += __mul24((int)chA, dlA) + __mul24((int)chB, dlB);
-                        cum_l0 += chA ? dS_A : 0.;  // :500, in step order (x + 0.0 is x: the running sum is never -0.0)
-                        cum_l0 += chB ? dS_B : 0.;
+                        // :500, in step order; a step that does not move adds +0.0 (x + 0.0 is x: the running sum is never -0.0)
+                        cum_l0 += __hiloint2double(dS_A_hi & (int)mA, dS_A_lo & (int)mA);
+                        cum_l0 += __hiloint2double(dS_B_hi & (int)mB, dS_B_lo & (int)mB);
                         wfence();
                     }
                     FSTAMP_STEP(8);
@@ -846,15 +869,17 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                     // steps that need the general path (bit 31 of prop_l) go one at a time
                     const unsigned long long gen_mask = __builtin_amdgcn_ballot_w64((int32_t)prop_l < 0);
                     uint32_t q = 0;
+                    acc_chunk = 0;
                     while (q < cnt) {
                         const uint32_t two = (uint32_t)(gen_mask >> q) & 3u;
                         if (__builtin_expect((two & 1u) != 0u, 0)) {
                             step_general(q, T_const);
                             q += 1u;
                         } else {
-                            q += step_pair(q, q + 1u < cnt ? (two >> 1) ^ 1u : 0u);
+                            q += step_pair(q, ((two >> 1) ^ 1u) & sflag(cnt - 1u - q));
                         }
                     }
+                    acc_l0 += (unsigned long long)acc_chunk;
                 } else {
                     for (uint32_t q = 0; q < cnt; ++q) step(std::false_type{}, q);
                 }
