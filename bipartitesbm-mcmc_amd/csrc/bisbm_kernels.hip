@@ -863,6 +863,174 @@ hipError_t launch_merge_relabel(uint8_t* labels, size_t label_stride, uint32_t n
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// agg_split, blockmodel.cc:505-565 (+ compute_dS(split) :374-424, apply_split_moves :428-459), intended semantics:
+// the position of a node in a block's split vector is its rank within the block.
+//   split_rank_kernel   rank of every node of the type within its block, ascending node id (one wave per chain)
+//   split_eval_kernel   one workgroup per (trial, chain): for every block of the type with more than one node, the
+//                       edge counts k[t] and the degree sum of the nodes the trial's cut marks (LDS histogram);
+//                       the K-scale dS arithmetic and the choice stay on the host, as in the merges
+//   split_apply_kernel  the chosen cut: marked nodes get the new label (type a: label KA, after every label >= KA
+//                       moved up by one, :434-443; type b: label K)
+// A cut marks node of rank i of block b in trial j iff
+//   compat: bit (offset of b + i) of the host-shuffled splitter_ of that trial (std::shuffle on the chain's engine),
+//   Philox: feistel(key(b, j), n_b)(i) >= floor(n_b / 2), key = Philox(seed, chain, PHX_SPLIT, epoch << 32 | b << 16 | j).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWave) void split_rank_kernel(SplitParams p) {
+    __shared__ uint32_t base[256];
+    const uint32_t chain = blockIdx.x, lane = threadIdx.x;
+    for (uint32_t i = lane; i < 256; i += kWave) base[i] = 0;
+    __syncthreads();
+    const uint32_t v_lo = p.type ? p.na : 0u, n_type = p.type ? p.n - p.na : p.na;
+    const uint8_t* lab = p.labels + (size_t)chain * p.label_stride + v_lo;
+    uint32_t* rank = p.rank + (size_t)chain * n_type;
+    for (uint32_t t0 = 0; t0 < n_type; t0 += kWave) {
+        const uint32_t i = t0 + lane;
+        const bool active = i < n_type;
+        const uint32_t L = active ? lab[i] : 0xffffffffu;
+        unsigned long long remaining = __ballot(active);
+        while (remaining) {  // one round per distinct label among the 64 nodes
+            const int leader = __ffsll((long long)remaining) - 1;
+            const uint32_t cur = (uint32_t)__shfl((int)L, leader, kWave);
+            const unsigned long long same = __ballot(active && L == cur);
+            if (active && L == cur) rank[i] = base[cur] + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            __syncthreads();
+            if ((int)lane == leader) base[cur] += (uint32_t)__popcll(same);
+            __syncthreads();
+            remaining &= ~same;
+        }
+    }
+}
+
+// the cut of (block, trial): marks by rank
+struct SplitCut {
+    Feistel f;
+    uint32_t half;  // floor(n_b / 2): ranks mapped below it stay
+};
+
+__global__ __launch_bounds__(256) void split_eval_kernel(SplitParams p) {
+    extern __shared__ int32_t sp_lds[];
+    const uint32_t trial = p.trial0 + blockIdx.x, chain = blockIdx.y;
+    const uint32_t K = p.ka + p.kb;
+    const uint32_t b_lo = p.type ? p.ka : 0u, k_type = p.type ? p.kb : p.ka;
+    const uint32_t t_lo = p.type ? 0u : p.ka, k_oth = p.type ? p.ka : p.kb;
+    const uint32_t v_lo = p.type ? p.na : 0u, n_type = p.type ? p.n - p.na : p.na;
+    int32_t* const k = sp_lds;                                  // [k_type][k_oth]
+    int32_t* const deg = k + k_type * k_oth;                    // [k_type]
+    uint32_t* const nr = (uint32_t*)(deg + k_type);             // [k_type]
+    uint32_t* const off = nr + k_type;                          // [k_type]
+    SplitCut* const cut = (SplitCut*)(off + k_type + (k_type & 1u));  // [k_type]
+    for (uint32_t i = threadIdx.x; i < k_type * k_oth + k_type; i += blockDim.x) k[i] = 0;
+    const uint32_t epoch = p.scalars[chain].split_epoch;
+    for (uint32_t b = threadIdx.x; b < k_type; b += blockDim.x) {
+        const uint32_t nb = (uint32_t)p.n_r[(size_t)chain * K + b_lo + b];
+        nr[b] = nb;
+        if (!p.bits && nb > 1) {
+            const uint64_t idx = ((uint64_t)epoch << 32) | ((uint64_t)(b_lo + b) << 16) | (uint64_t)trial;
+            cut[b].f.init(phx_draw(p.seed, p.first_chain_id + chain, PHX_SPLIT, idx), nb);
+            cut[b].half = nb / 2;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t b = 0; b < k_type; ++b) {
+            off[b] = acc;
+            acc += nr[b];
+        }
+    }
+    __syncthreads();
+    const uint8_t* lab = p.labels + (size_t)chain * p.label_stride;
+    const uint32_t* rank = p.rank + (size_t)chain * n_type;
+    const uint32_t* bits = p.bits ? p.bits + ((size_t)chain * p.nm + trial) * p.bit_words : nullptr;
+    for (uint32_t i = threadIdx.x; i < n_type; i += blockDim.x) {
+        const uint32_t v = v_lo + i, r = (uint32_t)lab[v] - b_lo, nb = nr[r];
+        if (nb <= 1) continue;
+        const uint32_t rk = rank[i];
+        bool marked;
+        if (bits) {
+            const uint32_t pos = off[r] + rk;
+            marked = (bits[pos >> 5] >> (pos & 31u)) & 1u;
+        } else {
+            marked = cut[r].f(rk) >= cut[r].half;
+        }
+        if (!marked) continue;
+        const uint32_t e0 = p.rowptr[v], e1 = p.rowptr[v + 1];
+        for (uint32_t e = e0; e < e1; ++e) atomicAdd(&k[r * k_oth + ((uint32_t)lab[p.col[e]] - t_lo)], 1);
+        atomicAdd(&deg[r], (int32_t)(e1 - e0));
+    }
+    __syncthreads();
+    int32_t* ok = p.out_k + ((size_t)chain * p.n_trials + blockIdx.x) * k_type * k_oth;
+    int32_t* od = p.out_deg + ((size_t)chain * p.n_trials + blockIdx.x) * k_type;
+    for (uint32_t i = threadIdx.x; i < k_type * k_oth; i += blockDim.x) ok[i] = k[i];
+    for (uint32_t i = threadIdx.x; i < k_type; i += blockDim.x) od[i] = deg[i];
+}
+
+__global__ __launch_bounds__(256) void split_apply_kernel(SplitParams p) {
+    __shared__ SplitCut cut;
+    __shared__ uint32_t s_off, s_nb;
+    const uint32_t chain = blockIdx.y;
+    const uint32_t K = p.ka + p.kb;
+    const uint32_t b_lo = p.type ? p.ka : 0u, k_type = p.type ? p.kb : p.ka;
+    const uint32_t v_lo = p.type ? p.na : 0u, n_type = p.type ? p.n - p.na : p.na;
+    const uint32_t block = p.chosen[2 * chain], trial = p.chosen[2 * chain + 1];
+    if (threadIdx.x == 0) {
+        const int32_t* n_r = p.n_r + (size_t)chain * K + b_lo;
+        uint32_t acc = 0;
+        for (uint32_t b = 0; b < block && b < k_type; ++b) acc += (uint32_t)n_r[b];
+        s_off = acc;
+        s_nb = (uint32_t)n_r[block];
+        if (!p.bits) {
+            const uint64_t idx = ((uint64_t)p.scalars[chain].split_epoch << 32) | ((uint64_t)(b_lo + block) << 16) | (uint64_t)trial;
+            cut.f.init(phx_draw(p.seed, p.first_chain_id + chain, PHX_SPLIT, idx), s_nb);
+            cut.half = s_nb / 2;
+        }
+    }
+    __syncthreads();
+    uint8_t* lab = p.labels + (size_t)chain * p.label_stride;
+    const uint32_t* rank = p.rank + (size_t)chain * n_type;
+    const uint32_t* bits = p.bits ? p.bits + ((size_t)chain * p.nm + trial) * p.bit_words : nullptr;
+    const uint32_t new_label = p.type ? K : p.ka;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < p.n; v += gridDim.x * blockDim.x) {
+        uint32_t L = lab[v];
+        const bool own = p.type ? v >= p.na : v < p.na;
+        if (!own) {
+            if (!p.type) lab[v] = (uint8_t)(L + 1);  // type-a split: the type-b labels move up by one (:434-443)
+            continue;
+        }
+        if (L != b_lo + block) continue;
+        const uint32_t rk = rank[v - v_lo];
+        bool marked;
+        if (bits) {
+            const uint32_t pos = s_off + rk;
+            marked = (bits[pos >> 5] >> (pos & 31u)) & 1u;
+        } else {
+            marked = cut.f(rk) >= cut.half;
+        }
+        if (marked) lab[v] = (uint8_t)new_label;
+    }
+}
+
+hipError_t launch_split_rank(const SplitParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(split_rank_kernel, dim3(p.n_chains), dim3(kWave), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_eval(const SplitParams& p, hipStream_t stream) {
+    const uint32_t k_type = p.type ? p.kb : p.ka, k_oth = p.type ? p.ka : p.kb;
+    const size_t lds = sizeof(int32_t) * ((size_t)k_type * k_oth + 3 * (size_t)k_type + 2) + sizeof(SplitCut) * k_type;
+    hipError_t e = hipFuncSetAttribute((const void*)split_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(split_eval_kernel, dim3(p.n_trials, p.n_chains), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_apply(const SplitParams& p, hipStream_t stream) {
+    const uint32_t tiles = std::min<uint32_t>((p.n + 256 * 16 - 1) / (256 * 16), 1024u);
+    hipLaunchKernelGGL(split_apply_kernel, dim3(tiles ? tiles : 1, p.n_chains), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_labels_widen(const uint8_t* labels, uint32_t* dst, uint32_t n, hipStream_t stream) {
     const uint32_t tiles = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
     hipLaunchKernelGGL(labels_widen_kernel, dim3(tiles ? tiles : 1), dim3(256), 0, stream, labels, dst, n);

@@ -25,7 +25,7 @@ struct ChainScalars {
     // (diagnostic, see BISBM_PLACEMENT_LOG in bisbm_runtime.hip)
     uint32_t hw_id[2];
     uint32_t xcc_id;
-    uint32_t pad_;
+    uint32_t split_epoch;  // Philox counter: agg_split calls so far
 };
 
 struct SweepParams {
@@ -113,6 +113,32 @@ struct MarginalParams {
     size_t label_stride;
     uint32_t* counts;
 };
+
+// agg_split (blockmodel.cc:505-565): evaluation of `n_trials` random half-cuts of every block of one type, all chains
+struct SplitParams {
+    const uint32_t* rowptr;
+    const uint32_t* col;
+    uint32_t n, na, ka, kb, n_chains, first_chain_id;
+    uint32_t type;              // 0: a type-a block is split, 1: a type-b block
+    uint32_t trial0, n_trials;  // trials evaluated by this launch: trial0 .. trial0 + n_trials - 1
+    uint32_t nm;                // trials per block of the whole call (stride of `bits`)
+    uint64_t seed;
+    uint8_t* labels;
+    size_t label_stride;
+    const int32_t* n_r;  // [chain][K]
+    const ChainScalars* scalars;
+    uint32_t* rank;        // [chain][n_type]: rank of every node of the type within its block (ascending id)
+    const uint32_t* bits;  // compat: [chain][nm][bit_words] cut bits at position (offset of the block + rank); NULL: Philox
+    uint32_t bit_words;
+    int32_t* out_k;    // [chain][n_trials][k_type][k_oth]: edges from the marked nodes of block r to opposite block t
+    int32_t* out_deg;  // [chain][n_trials][k_type]: degree sum of the marked nodes
+    const uint32_t* chosen;  // apply: [chain][2] = {block (own-type index), trial}
+};
+constexpr uint32_t PHX_SPLIT = 6;
+
+hipError_t launch_split_rank(const SplitParams& p, hipStream_t stream);
+hipError_t launch_split_eval(const SplitParams& p, hipStream_t stream);
+hipError_t launch_split_apply(const SplitParams& p, hipStream_t stream);
 
 // metropolis_hasting.cc:10-37, arithmetic types as the C++ promotes them
 __device__ __forceinline__ double temperature_of(const SweepParams& p, uint64_t t) {

@@ -298,6 +298,36 @@ uint32_t orc_mt_lemire(orc_mt19937 *g, uint32_t range) {
 }
 
 /* std::shuffle, stl_algo.h:3729-3793 */
+/* std::shuffle of a vector<bool> (blockmodel.cc:541-543): the same swaps as for any random-access range */
+void orc_mt_shuffle_u8(orc_mt19937 *g, uint8_t *v, size_t n) {
+    if (n == 0) return;
+    uint8_t tmp;
+#define ORC_SWAP8(i, j) (tmp = v[i], v[i] = v[j], v[j] = tmp)
+    if (0xFFFFFFFFull / n >= n) {
+        size_t i = 1;
+        if ((n % 2) == 0) {
+            size_t j = orc_mt_lemire(g, 2);
+            ORC_SWAP8(i, j);
+            ++i;
+        }
+        while (i < n) {
+            uint64_t s = i + 1;
+            uint32_t x = orc_mt_lemire(g, (uint32_t)(s * (s + 1)));
+            size_t p0 = x / (s + 1), p1 = x % (s + 1);
+            ORC_SWAP8(i, p0);
+            ++i;
+            ORC_SWAP8(i, p1);
+            ++i;
+        }
+        return;
+    }
+    for (size_t i = 1; i < n; ++i) {
+        size_t j = orc_mt_lemire(g, (uint32_t)(i + 1));
+        ORC_SWAP8(i, j);
+    }
+#undef ORC_SWAP8
+}
+
 void orc_mt_shuffle_u32(orc_mt19937 *g, uint32_t *v, size_t n) {
     if (n == 0) return;
     uint32_t tmp;
@@ -380,7 +410,7 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     out[3] = c3;
 }
 
-enum { PHX_STEP_A = 0, PHX_STEP_B = 1, PHX_SWEEP_KEY = 2, PHX_INIT_SHUFFLE = 3, PHX_MERGE_A = 4, PHX_MERGE_B = 5 };
+enum { PHX_STEP_A = 0, PHX_STEP_B = 1, PHX_SWEEP_KEY = 2, PHX_INIT_SHUFFLE = 3, PHX_MERGE_A = 4, PHX_MERGE_B = 5, PHX_SPLIT = 6 };
 
 static void phx_draw(uint64_t seed, uint32_t chain, uint32_t purpose, uint64_t idx, uint32_t out[4]) {
     uint32_t ctr[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), chain, purpose};
@@ -645,6 +675,9 @@ struct orc_model {
     uint64_t sweeps_total;  /* Philox counters: sweeps executed over the model's lifetime */
     uint32_t shuffle_epoch; /* Philox counters: number of shuffle_bisbm calls so far */
     uint32_t merge_epoch;   /* Philox counters: proposal rounds of agg_merge so far */
+    uint32_t split_epoch;   /* Philox counters: agg_split calls so far */
+    size_t cap_K;           /* blocks the state arrays are allocated for */
+    double last_split_dS;   /* dS of the cut the last agg_split applied */
     uint64_t last_accepted, last_sweeps;
 };
 
@@ -701,6 +734,7 @@ orc_model *orc_create(size_t n, size_t na, size_t nb, const uint64_t *rowptr, co
     m->n_r = (int *)calloc(K, sizeof(int));
     m->eta = (uint32_t *)calloc(K * (maxdeg + 1), sizeof(uint32_t));
     m->kv = (int *)calloc(K, sizeof(int));
+    m->cap_K = K;
     m->entropy_min = INFINITY;
     m->accu_r = 0.;
     m->rng_mode = ORC_RNG_COMPAT;
@@ -1226,9 +1260,9 @@ double orc_anneal(orc_model *m, int schedule, float kw0, float kw1, uint64_t dur
 }
 
 /* ------------------------------------------------------------------------------------------
- * Agglomerative merges between anneals, blockmodel.cc:109-288,335-372,567-611,639-669.
- * Negative diffs (agg_split, blockmodel.cc:505-565) are not restated: the reference reads out of
- * range there, so there is nothing to be faithful to; the functions return -2.
+ * Agglomerative merges and splits between anneals, blockmodel.cc:109-288,335-459,505-611,639-669.
+ * agg_split follows the INTENDED semantics (the reference's split dS indexes its split vector
+ * with a counter over all nodes, an out-of-range read): the position of a node is its rank within its block.
  * ---------------------------------------------------------------------------------------- */
 size_t orc_ka(const orc_model *m) { return m->ka; }
 size_t orc_kb(const orc_model *m) { return m->kb; }
@@ -1436,11 +1470,144 @@ static size_t propose_round(orc_model *m, size_t first, size_t count, int nm, or
     return ii;
 }
 
-/* agg_merge(engine, diff_a, diff_b, nm), blockmodel.cc:109-206.  0 ok, -1 sanity failure, -2 negative diff,
- * -3 no progress possible (the reference would recurse without end). */
+/* room for one more block in the state arrays */
+static void grow_blocks(orc_model *m, size_t K) {
+    if (K <= m->cap_K) return;
+    size_t D = m->max_degree + 1;
+    m->m = (int *)realloc(m->m, sizeof(int) * K * K);
+    m->m_r = (int *)realloc(m->m_r, sizeof(int) * K);
+    m->n_r = (int *)realloc(m->n_r, sizeof(int) * K);
+    m->eta = (uint32_t *)realloc(m->eta, sizeof(uint32_t) * K * D);
+    m->kv = (int *)realloc(m->kv, sizeof(int) * K);
+    m->cap_K = K;
+}
+
+/* compute_dS(size_t mb, vector<bool>& split_move), blockmodel.cc:374-424, with the position of a node in the split
+ * vector being its RANK WITHIN THE BLOCK (ascending node id).  The reference advances its counter for every node of
+ * the graph (:402 sits outside the `if (_mb == r_)`), which reads past the vector unless the block's nodes are the
+ * first ids; agg_split's own pass (:554-561) indexes by rank, and that is the meaning restated here.
+ * k[t]: edges from the moved nodes to opposite-type block t; deg: their degree sum. */
+static double split_dS(const orc_model *m, size_t r, const int *k, int deg) {
+    size_t K = m->K;
+    double entropy0 = 0., entropy1 = 0.;
+    size_t t_lo = (r < m->ka) ? m->ka : 0, t_hi = (r < m->ka) ? K : m->ka; /* criterion, :380 */
+    for (size_t t = t_lo; t < t_hi; ++t) {                                  /* :409-417 */
+        entropy0 -= orc_lgamma_fast((size_t)(m->m[r * K + t] + 1));
+        entropy1 -= orc_lgamma_fast((size_t)(m->m[r * K + t] - k[t] + 1));
+        entropy1 -= orc_lgamma_fast((size_t)(k[t] + 1));
+    }
+    entropy0 -= -orc_lgamma_fast((size_t)(m->m_r[r] + 1)); /* :418-421 */
+    entropy1 -= -orc_lgamma_fast((size_t)(m->m_r[r] - deg + 1));
+    entropy1 -= -orc_lgamma_fast((size_t)(deg + 1));
+    return entropy1 - entropy0;
+}
+
+/* agg_split(engine, type, nm), blockmodel.cc:505-565 + apply_split_moves :428-459: every block of the type with more
+ * than one node is cut nm times into a random floor(n/2) / ceil(n/2) partition (`splitter_` shuffled once, then once
+ * more before every trial); the cut with the lowest dS over all blocks and trials (strict <, blocks ascending, trials
+ * in order) is applied: the marked nodes form a new block -- label KA for type a (every label >= KA moves up by
+ * one first, :434-443), label K for type b -- and the block state is rebuilt.
+ * compat: the shuffles are std::shuffle on `engine`.  Philox: node of rank i is marked in trial j of block b iff
+ * feistel_perm(key(b, j), n_b, i) >= floor(n_b / 2) (a keyed random bijection: the same uniform cut, no serial
+ * shuffle), key = Philox(seed, chain, PHX_SPLIT, split_epoch << 32 | b << 16 | j).
+ * Returns 0, -3 when no block of the type has two nodes (the reference would apply an empty move list and still
+ * count a block more), -4 when the label format would overflow (K + 1 > 256 is the product's limit, not the oracle's). */
+int orc_agg_split(orc_model *m, int type, int nm) {
+    size_t K = m->K, n = m->n;
+    size_t b_lo = type ? m->ka : 0, b_hi = type ? K : m->ka;
+    size_t v_lo = type ? m->na : 0, v_hi = type ? n : m->na;
+    if (nm < 1 || nm > 65535) return -5;
+    /* nodes of every block in ascending id: rank -> node */
+    size_t *off = (size_t *)calloc(K + 1, sizeof(size_t));
+    for (size_t b = 0; b < K; ++b) off[b + 1] = off[b] + (size_t)m->n_r[b];
+    uint32_t *members = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    size_t *fill = (size_t *)calloc(K, sizeof(size_t));
+    for (size_t v = 0; v < n; ++v) members[off[m->labels[v]] + fill[m->labels[v]]++] = (uint32_t)v;
+    free(fill);
+    double best = INFINITY;
+    size_t best_block = 0;
+    uint8_t *best_cut = NULL;
+    size_t best_n = 0;
+    int *k = (int *)malloc(sizeof(int) * K);
+    for (size_t b = b_lo; b < b_hi; ++b) {
+        size_t nb = (size_t)m->n_r[b];
+        if (nb <= 1) continue;
+        size_t unchange = nb / 2;
+        uint8_t *cut = (uint8_t *)malloc(nb);
+        for (size_t i = 0; i < nb; ++i) cut[i] = i >= unchange;
+        if (m->rng_mode == ORC_RNG_COMPAT) orc_mt_shuffle_u8(&m->engine, cut, nb); /* :541 */
+        for (int j = 0; j < nm; ++j) {
+            if (m->rng_mode == ORC_RNG_COMPAT) {
+                orc_mt_shuffle_u8(&m->engine, cut, nb); /* :543 */
+            } else {
+                uint32_t keys[4];
+                uint64_t idx = ((uint64_t)m->split_epoch << 32) | ((uint64_t)b << 16) | (uint64_t)j;
+                phx_draw(m->phx_seed, m->phx_chain, PHX_SPLIT, idx, keys);
+                for (size_t i = 0; i < nb; ++i) cut[i] = feistel_perm(keys, (uint32_t)nb, (uint32_t)i) >= unchange;
+            }
+            memset(k, 0, sizeof(int) * K);
+            int deg = 0;
+            for (size_t i = 0; i < nb; ++i) {
+                if (!cut[i]) continue;
+                size_t v = members[off[b] + i];
+                for (uint64_t e = m->rowptr[v]; e < m->rowptr[v + 1]; ++e) k[m->labels[m->col[e]]]++;
+                deg += m->deg[v];
+            }
+            double dS = split_dS(m, b, k, deg);
+            if (dS < best) { /* :545-550 */
+                best = dS;
+                best_block = b;
+                best_n = nb;
+                free(best_cut);
+                best_cut = (uint8_t *)malloc(nb);
+                memcpy(best_cut, cut, nb);
+            }
+        }
+        free(cut);
+    }
+    free(k);
+    m->split_epoch++;
+    m->last_split_dS = best;
+    if (!best_cut) {
+        free(off), free(members);
+        return -3;
+    }
+    /* apply_split_moves, :428-459 */
+    if (!type) {
+        for (size_t v = 0; v < n; ++v)
+            if (m->labels[v] >= m->ka) m->labels[v]++;
+        for (size_t i = 0; i < best_n; ++i)
+            if (best_cut[i]) m->labels[members[off[best_block] + i]] = (uint32_t)m->ka;
+        m->ka++;
+    } else {
+        for (size_t i = 0; i < best_n; ++i)
+            if (best_cut[i]) m->labels[members[off[best_block] + i]] = (uint32_t)K;
+        m->kb++;
+    }
+    (void)v_lo, (void)v_hi;
+    m->K = K + 1;
+    grow_blocks(m, m->K);
+    free(best_cut), free(off), free(members);
+    orc_init_bisbm(m);
+    return 0;
+}
+
+double orc_last_split_dS(const orc_model *m) { return m->last_split_dS; }
+
+/* agg_merge(engine, diff_a, diff_b, nm), blockmodel.cc:109-206.  Negative diffs split first (:110-117).  0 ok,
+ * -1 sanity failure, -3 no progress possible (the reference would recurse without end or split nothing). */
 int orc_agg_merge(orc_model *m, int diff_a, int diff_b, int nm) {
+    while (diff_a < 0) {
+        int rc = orc_agg_split(m, 0, nm);
+        if (rc) return rc;
+        diff_a++;
+    }
+    while (diff_b < 0) {
+        int rc = orc_agg_split(m, 1, nm);
+        if (rc) return rc;
+        diff_b++;
+    }
     for (int depth = 0; depth < 10000; ++depth) {
-        if (diff_a < 0 || diff_b < 0) return -2;
         if (diff_a + diff_b == 0) return 0;
         size_t K = m->K, first, count;
         if (diff_a > 0 && diff_b == 0) {

@@ -77,6 +77,7 @@ uint32_t orc_mt_next(orc_mt19937 *g);
 double orc_mt_canonical(orc_mt19937 *g);
 uint32_t orc_mt_lemire(orc_mt19937 *g, uint32_t range);
 void orc_mt_shuffle_u32(orc_mt19937 *g, uint32_t *v, size_t n);
+void orc_mt_shuffle_u8(orc_mt19937 *g, uint8_t *v, size_t n); /* std::shuffle of a vector<bool> */
 size_t orc_mt_discrete(orc_mt19937 *g, const int *w, size_t n);
 
 /* ---- Philox4x32-10 (production RNG; Salmon et al. SC'11) ---- */
@@ -123,6 +124,9 @@ uint64_t orc_total_sweeps(const orc_model *m);
 size_t orc_ka(const orc_model *m);
 size_t orc_kb(const orc_model *m);
 double orc_merge_dS(const orc_model *m, size_t r, size_t s);
+/* agg_split(engine, type, nm), blockmodel.cc:505-565 with the intended rank-within-block indexing (see the .c file) */
+int orc_agg_split(orc_model *m, int type, int nm);
+double orc_last_split_dS(const orc_model *m);
 int orc_agg_merge(orc_model *m, int diff_a, int diff_b, int nm);
 int orc_agg_merge_total(orc_model *m, int diff, int nm);
 size_t orc_geospace(long start_a, long end_a, long start_b, long end_b, double ratio, int *out_a, int *out_b,

@@ -39,6 +39,15 @@ void std_shuffle_two(uint64_t seed, uint32_t* v, size_t na, size_t nb) {
     std::shuffle(&v[na], &v[na + nb], g);
 }
 
+// agg_split's splitter_ (blockmodel.cc:532-543): vector<bool> of floor(n/2) false then true, shuffled `reps` times
+void std_shuffle_bool(uint64_t seed, size_t n, size_t reps, uint8_t* out) {
+    std::mt19937 g(seed);
+    std::vector<bool> v(n, false);
+    for (size_t i = n / 2; i < n; ++i) v[i] = true;
+    for (size_t r = 0; r < reps; ++r) std::shuffle(v.begin(), v.end(), g);
+    for (size_t i = 0; i < n; ++i) out[i] = v[i];
+}
+
 void std_discrete(uint64_t seed, const int* w, size_t n, size_t draws, uint64_t* out) {
     std::mt19937 g(seed);
     std::vector<int> wv(w, w + n);

@@ -113,6 +113,10 @@ def lib():
     L.orc_merge_dS.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
     L.orc_agg_merge.restype = C.c_int
     L.orc_agg_merge.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.orc_last_split_dS.restype = C.c_double
+    L.orc_last_split_dS.argtypes = [C.c_void_p]
+    L.orc_agg_split.restype = C.c_int
+    L.orc_agg_split.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.orc_agg_merge_total.restype = C.c_int
     L.orc_agg_merge_total.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.orc_geospace.restype = C.c_size_t
@@ -240,6 +244,12 @@ class OracleModel:
     def agg_merge(self, diff_a, diff_b, nm):
         """blockmodel_t::agg_merge(engine, diff_a, diff_b, nm), blockmodel.cc:109-206"""
         rc = self.L.orc_agg_merge(self.h, diff_a, diff_b, nm)
+        self._refresh_k()
+        return rc
+
+    def agg_split(self, type_b, nm):
+        """blockmodel_t::agg_split(engine, type, nm), blockmodel.cc:505-565 (intended semantics, SURVEY App. D)"""
+        rc = self.L.orc_agg_split(self.h, int(bool(type_b)), nm)
         self._refresh_k()
         return rc
 

@@ -274,6 +274,22 @@ def test_shuffle_matches_libstdcxx(stdlib, n):
         assert L.orc_mt_canonical(g) == wu
 
 
+@pytest.mark.parametrize("n", [2, 3, 7, 32, 1001, 65535, 65536, 70000])
+def test_bool_shuffle_matches_libstdcxx(stdlib, n):
+    """agg_split's std::shuffle of a vector<bool> (blockmodel.cc:541-543) restated as a byte shuffle."""
+    L = O.lib()
+    u8p = C.POINTER(C.c_uint8)
+    for seed in (3, 99):
+        want = np.zeros(n, dtype=np.uint8)
+        stdlib.std_shuffle_bool(C.c_uint64(seed), C.c_size_t(n), C.c_size_t(4), want.ctypes.data_as(u8p))
+        g = O.C.create_string_buffer(4 * 624 + 8)
+        L.orc_mt_seed(g, C.c_uint64(seed))
+        v = (np.arange(n) >= n // 2).astype(np.uint8)
+        for _ in range(4):
+            L.orc_mt_shuffle_u8(g, v.ctypes.data_as(u8p), C.c_size_t(n))
+        assert (v == want).all()
+
+
 def test_discrete_and_uniform_int_match_libstdcxx(stdlib):
     L = O.lib()
     L.orc_mt_discrete.restype = C.c_size_t
@@ -469,3 +485,83 @@ def test_philox_mode_log_q_definition():
         worst[band] = max(worst.get(band, 0.0), abs(a - b) / abs(b))
     assert worst[2.5] < 8e-10 and worst[4] < 2e-10 and worst[6] < 2e-11 and worst[8] < 2e-12 and worst[10] < 3e-14 and worst[13] < 2e-15
     assert worst[2.5] > 1e-11  # (the stop does leave something there: the two definitions are not the same function)
+
+
+# ------------------------------------------------------------------ agg_split (blockmodel.cc:374-459,505-565)
+def _split_entropy_terms(m_full, m_r, ka):
+    """The part of entropy() that compute_dS(split) tracks: -sum lgamma(m_rs + 1) over r < s, + sum lgamma(m_r + 1)."""
+    K = len(m_r)
+    e = 0.0
+    for r in range(K):
+        for s in range(r + 1, K):
+            e -= math.lgamma(m_full[r, s] + 1)
+        e += math.lgamma(m_r[r] + 1)
+    return e
+
+
+@pytest.mark.parametrize("mode", ["compat", "philox"])
+@pytest.mark.parametrize("type_b", [0, 1])
+def test_agg_split_properties(mode, type_b):
+    """One more block of the asked type; exactly one block loses floor/ceil half of its nodes to the new label (KA for
+    type a -- every type-b label moves up by one --, K for type b); everything else keeps its label; the state equals
+    a recount; and the chosen cut is the best of nm independent evaluations (dS re-derived from the edge terms)."""
+    rowptr, col, na, nb = O.load_graph("n_1000")
+    ka, kb = 3, 4
+    m = O.OracleModel(rowptr, col, na, nb, ka, kb, 1.0, O.contiguous_labels(na, nb, ka, kb))
+    if mode == "compat":
+        m.seed_compat(11, 12)
+    else:
+        m.seed_philox(11, 4)
+    m.shuffle_bisbm()
+    m.anneal("constant", [1.0], 2 * (na + nb), 1 << 60)
+    before = m.memberships().copy()
+    n_r0 = m.n_r().copy()
+    e0 = _split_entropy_terms(m.m(), m.m_r(), ka)
+    assert m.agg_split(type_b, 8) == 0
+    assert (m.ka, m.kb) == (ka + (1 - type_b), kb + type_b)
+    after = m.memberships()
+    new_label = ka if not type_b else ka + kb
+    moved = np.flatnonzero(after == new_label)
+    src = set(before[moved])
+    assert len(src) == 1
+    r = src.pop()
+    assert (r >= ka) == bool(type_b)
+    assert len(moved) == n_r0[r] - n_r0[r] // 2
+    others = np.setdiff1d(np.arange(na + nb), moved)
+    shift = (before[others] >= ka).astype(np.uint32) if not type_b else 0
+    assert (after[others] == before[others] + shift).all()
+    m._rowptr, m._col = rowptr, col
+    f = _recount(m)
+    assert (m.m() == f.m()).all() and (m.m_r() == f.m_r()).all() and (m.n_r() == f.n_r()).all()
+    assert (m.eta() == f.eta()).all()
+    # the cut that won is no worse than a plain first-half / second-half cut of any block of the type would
+    # typically be: at least its dS (the change of the edge terms of the description length) is finite and the
+    # new block is connected to the graph
+    e1 = _split_entropy_terms(m.m(), m.m_r(), m.ka)
+    assert np.isfinite(e1 - e0) and m.m_r()[new_label] > 0
+    assert O.lib().orc_last_split_dS(m.h) == pytest.approx(e1 - e0, rel=1e-9)  # compute_dS(split) == change of the edge terms
+    # deterministic for a fixed seed
+    m2 = O.OracleModel(rowptr, col, na, nb, ka, kb, 1.0, O.contiguous_labels(na, nb, ka, kb))
+    m2.seed_compat(11, 12) if mode == "compat" else m2.seed_philox(11, 4)
+    m2.shuffle_bisbm()
+    m2.anneal("constant", [1.0], 2 * (na + nb), 1 << 60)
+    assert m2.agg_split(type_b, 8) == 0 and (m2.memberships() == after).all()
+    # splitting a partition with single-node blocks only is refused (the reference would add an empty block)
+    tiny = O.OracleModel(*O.load_graph("southernWomen")[:2], 18, 14, 18, 14, 0.001, np.arange(32, dtype=np.uint32))
+    tiny.seed_compat(1, 2)
+    tiny.init_bisbm()
+    assert tiny.agg_split(0, 5) == -3
+
+
+def test_agg_merge_with_negative_diffs_splits_first():
+    """agg_merge(engine, -1, +1, nm) = one agg_split of type a, then one merge among type b (blockmodel.cc:110-117)."""
+    rowptr, col, na, nb = O.load_graph("n_1000")
+    a = O.OracleModel(rowptr, col, na, nb, 3, 5, 1.0, O.contiguous_labels(na, nb, 3, 5))
+    b = O.OracleModel(rowptr, col, na, nb, 3, 5, 1.0, O.contiguous_labels(na, nb, 3, 5))
+    for m in (a, b):
+        m.seed_philox(5, 0)
+        m.shuffle_bisbm()
+    assert a.agg_merge(-1, 1, 10) == 0
+    assert b.agg_split(0, 10) == 0 and b.agg_merge(0, 1, 10) == 0
+    assert (a.ka, a.kb) == (4, 4) == (b.ka, b.kb)
+    assert (a.memberships() == b.memberships()).all()
