@@ -206,6 +206,8 @@ struct bisbm_engine {
     double* d_tmp_f64 = nullptr;  // n_chains doubles
     uint32_t* d_stage_u32 = nullptr;  // n uint32 staging
     uint32_t* d_counts = nullptr;     // internal marginal buffer n*kmax
+    uint32_t counts_kmax = 0;         // columns d_counts was sized for
+    uint32_t cap_ka = 0, cap_kb = 0;  // block counts d_m / d_m_r / d_n_r / d_eta are allocated for
     std::shared_ptr<HostTables> tab;
     uint32_t q_stride = 0;
     // chain-independent part of entropy()
@@ -343,6 +345,8 @@ int bisbm_create(bisbm_handle* out, uint64_t n, uint64_t na, uint64_t nb, const 
     h->seed = seed;
     h->gen_seed = gen_seed;
     h->label_stride = (n + 255) & ~(uint64_t)255;
+    h->cap_ka = ka;
+    h->cap_kb = kb;
 
     auto bail = [&](int code) {
         g_create_error = h->err;
@@ -765,8 +769,16 @@ int bisbm_entropy(bisbm_handle h, double* out) {
 int bisbm_marginals_reset(bisbm_handle h) {
     if (!h) return BISBM_ERR_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    const size_t cnt = (size_t)h->n * std::max(h->ka, h->kb);
-    if (!h->d_counts) HIPCHK(h, dalloc(&h->d_counts, cnt));
+    const uint32_t kmax = std::max(h->ka, h->kb);
+    const size_t cnt = (size_t)h->n * kmax;
+    if (h->d_counts && h->counts_kmax < kmax) {
+        (void)hipFree(h->d_counts);
+        h->d_counts = nullptr;
+    }
+    if (!h->d_counts) {
+        HIPCHK(h, dalloc(&h->d_counts, cnt));
+        h->counts_kmax = kmax;
+    }
     HIPCHK(h, hipMemsetAsync(h->d_counts, 0, sizeof(uint32_t) * cnt, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return BISBM_OK;
@@ -1121,14 +1133,232 @@ struct MergeChain {
     }
 };
 
+// blockmodel_t::agg_split(engine, type, nm), blockmodel.cc:505-565, in every chain (intended semantics: a node's position
+// in its block's split vector is its rank within the block).  Device: ranks, the edge counts of every
+// trial's cut (split_eval_kernel), the relabelling; host: the K-scale dS of every (block, trial) -- compute_dS(size_t,
+// vector<bool>&), :374-424, serial sums in source order -- and the choice (lowest dS, strict <, blocks ascending,
+// trials in order = lexicographic minimum of (dS, block, trial)).  mt19937-compat mode shuffles a real
+// std::vector<bool> with the chain's std::mt19937 (the reference's draw sequence by construction) and uploads the cuts.
+int run_split(bisbm_engine* h, int type, int nm) {
+    if (!h->state_ready) return fail(h, BISBM_ERR_STATE, "call bisbm_init or bisbm_shuffle before bisbm_agg_merge");
+    if (nm < 1 || nm > 65535) return fail(h, BISBM_ERR_INVALID_ARG, "nm must be in [1, 65535]");
+    if (h->K + 1 > 256) return fail(h, BISBM_ERR_UNSUPPORTED, "a split would give %u blocks (> 256: labels are stored as uint8)", h->K + 1);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t C = h->n_chains, K = h->K, ka = h->ka, kb = h->kb;
+    const size_t k_type = type ? kb : ka, k_oth = type ? ka : kb, b_lo = type ? ka : 0;
+    const size_t n_type = type ? h->nb : h->na;
+    const bool compat = h->rng_mode == BISBM_RNG_MT19937_COMPAT;
+
+    std::vector<int32_t> n_r(C * K), m_r(C * K), quad(C * ka * kb);
+    std::vector<ChainScalars> sc(C);
+    HIPCHK(h, hipMemcpy(n_r.data(), h->d_n_r, sizeof(int32_t) * n_r.size(), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(m_r.data(), h->d_m_r, sizeof(int32_t) * m_r.size(), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(quad.data(), h->d_m, sizeof(int32_t) * quad.size(), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(sc.data(), h->d_scalars, sizeof(ChainScalars) * C, hipMemcpyDeviceToHost));
+    for (size_t c = 0; c < C; ++c) {
+        bool any = false;
+        for (size_t b = 0; b < k_type; ++b) any |= n_r[c * K + b_lo + b] > 1;
+        if (!any)
+            return fail(h, BISBM_ERR_STATE, "chain %zu: no type-%c block has two nodes: nothing to split (the reference would add an empty block)",
+                        c, type ? 'b' : 'a');
+    }
+
+    uint32_t *d_rank = nullptr, *d_bits = nullptr, *d_chosen = nullptr;
+    int32_t *d_out_k = nullptr, *d_out_deg = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {(void*)d_rank, (void*)d_bits, (void*)d_chosen, (void*)d_out_k, (void*)d_out_deg})
+            if (p) (void)hipFree(p);
+    };
+#define SCHK(expr)                                                                 \
+    do {                                                                           \
+        hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess) {                                                    \
+            cleanup();                                                             \
+            return fail(h, BISBM_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+        }                                                                          \
+    } while (0)
+    SCHK(dalloc(&d_rank, C * n_type));
+    SCHK(dalloc(&d_chosen, 2 * C));
+
+    SplitParams sp{};
+    sp.rowptr = h->d_rowptr;
+    sp.col = h->d_col;
+    sp.n = (uint32_t)h->n;
+    sp.na = (uint32_t)h->na;
+    sp.ka = h->ka;
+    sp.kb = h->kb;
+    sp.n_chains = h->n_chains;
+    sp.first_chain_id = h->first_chain_id;
+    sp.type = (uint32_t)type;
+    sp.nm = (uint32_t)nm;
+    sp.seed = h->seed;
+    sp.labels = h->d_labels;
+    sp.label_stride = h->label_stride;
+    sp.n_r = h->d_n_r;
+    sp.scalars = h->d_scalars;
+    sp.rank = d_rank;
+    SCHK(launch_split_rank(sp, h->stream));
+
+    // mt19937-compat: the cuts come from std::shuffle on the chain's engine (:541-543), as bits at (block offset + rank)
+    std::vector<uint32_t> mt_e;
+    const size_t bit_words = (n_type + 31) / 32;
+    if (compat) {
+        if ((double)C * nm * bit_words * 4.0 > 2.0e9) {
+            cleanup();
+            return fail(h, BISBM_ERR_UNSUPPORTED, "mt19937-compat agg_split needs %.1f GB of cut bits; use fewer chains (compat is the parity path)",
+                        (double)C * nm * bit_words * 4.0 / 1e9);
+        }
+        mt_e.resize(C * 624);
+        SCHK(hipMemcpy(mt_e.data(), h->d_mt_engine, sizeof(uint32_t) * mt_e.size(), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> bits(C * (size_t)nm * bit_words, 0u);
+        for (size_t c = 0; c < C; ++c) {
+            std::mt19937 engine;
+            {
+                std::stringstream ss;
+                for (int i = 0; i < 624; ++i) ss << mt_e[c * 624 + i] << ' ';
+                ss << sc[c].engine_idx;
+                ss >> engine;
+            }
+            size_t off = 0;
+            for (size_t b = 0; b < k_type; ++b) {
+                const size_t nb = (size_t)n_r[c * K + b_lo + b];
+                if (nb > 1) {
+                    std::vector<bool> splitter(nb, false);  // :532-537
+                    for (size_t i = nb / 2; i < nb; ++i) splitter[i] = true;
+                    std::shuffle(splitter.begin(), splitter.end(), engine);  // :541
+                    for (int j = 0; j < nm; ++j) {
+                        std::shuffle(splitter.begin(), splitter.end(), engine);  // :543
+                        uint32_t* row = &bits[(c * (size_t)nm + (size_t)j) * bit_words];
+                        for (size_t i = 0; i < nb; ++i)
+                            if (splitter[i]) row[(off + i) >> 5] |= 1u << ((off + i) & 31);
+                    }
+                }
+                off += nb;
+            }
+            std::stringstream ss;
+            ss << engine;
+            for (int i = 0; i < 624; ++i) ss >> mt_e[c * 624 + i];
+            ss >> sc[c].engine_idx;
+        }
+        SCHK(dalloc(&d_bits, bits.size()));
+        SCHK(hipMemcpy(d_bits, bits.data(), sizeof(uint32_t) * bits.size(), hipMemcpyHostToDevice));
+        sp.bits = d_bits;
+        sp.bit_words = (uint32_t)bit_words;
+    }
+
+    // trials in batches of at most ~256 MB of counts
+    const size_t per_trial = C * k_type * k_oth * sizeof(int32_t);
+    const size_t batch = std::max<size_t>(1, std::min<size_t>((size_t)nm, ((size_t)256 << 20) / std::max<size_t>(per_trial, 1)));
+    SCHK(dalloc(&d_out_k, C * batch * k_type * k_oth));
+    SCHK(dalloc(&d_out_deg, C * batch * k_type));
+    sp.out_k = d_out_k;
+    sp.out_deg = d_out_deg;
+    std::vector<int32_t> out_k(C * batch * k_type * k_oth), out_deg(C * batch * k_type);
+    struct Best {
+        double dS = std::numeric_limits<double>::infinity();
+        uint32_t block = 0, trial = 0;
+        bool found = false;
+    };
+    std::vector<Best> best(C);
+    const std::vector<double>& lg = h->tab->lg;
+    for (size_t t0 = 0; t0 < (size_t)nm; t0 += batch) {
+        const size_t nt = std::min(batch, (size_t)nm - t0);
+        sp.trial0 = (uint32_t)t0;
+        sp.n_trials = (uint32_t)nt;
+        SCHK(launch_split_eval(sp, h->stream));
+        SCHK(hipStreamSynchronize(h->stream));
+        SCHK(hipMemcpy(out_k.data(), d_out_k, sizeof(int32_t) * C * nt * k_type * k_oth, hipMemcpyDeviceToHost));
+        SCHK(hipMemcpy(out_deg.data(), d_out_deg, sizeof(int32_t) * C * nt * k_type, hipMemcpyDeviceToHost));
+        for (size_t c = 0; c < C; ++c)
+            for (size_t b = 0; b < k_type; ++b) {
+                if (n_r[c * K + b_lo + b] <= 1) continue;
+                for (size_t j = 0; j < nt; ++j) {
+                    const int32_t* k = &out_k[((c * nt + j) * k_type + b) * k_oth];
+                    const int deg = out_deg[(c * nt + j) * k_type + b];
+                    // compute_dS(size_t mb, vector<bool>&), :404-423
+                    double entropy0 = 0., entropy1 = 0.;
+                    for (size_t t = 0; t < k_oth; ++t) {
+                        const int m_rt = type ? quad[(c * ka + t) * kb + b] : quad[(c * ka + b) * kb + t];
+                        entropy0 -= lg[(size_t)(m_rt + 1)];
+                        entropy1 -= lg[(size_t)(m_rt - k[t] + 1)];
+                        entropy1 -= lg[(size_t)(k[t] + 1)];
+                    }
+                    const int m0r = m_r[c * K + b_lo + b];
+                    entropy0 -= -lg[(size_t)(m0r + 1)];
+                    entropy1 -= -lg[(size_t)(m0r - deg + 1)];
+                    entropy1 -= -lg[(size_t)(deg + 1)];
+                    const double dS = entropy1 - entropy0;
+                    Best& B = best[c];
+                    const uint32_t trial = (uint32_t)(t0 + j);
+                    const bool better = dS < B.dS || (dS == B.dS && B.found && (b < B.block || (b == B.block && trial < B.trial)));
+                    if (better) {
+                        B.dS = dS;
+                        B.block = (uint32_t)b;
+                        B.trial = trial;
+                        B.found = true;
+                    }
+                }
+            }
+    }
+    std::vector<uint32_t> chosen(2 * C);
+    for (size_t c = 0; c < C; ++c) {
+        if (!best[c].found) {  // every dS was +inf or NaN: cannot happen with finite tables
+            cleanup();
+            return fail(h, BISBM_ERR_STATE, "chain %zu: no finite split dS", c);
+        }
+        chosen[2 * c] = best[c].block;
+        chosen[2 * c + 1] = best[c].trial;
+    }
+    SCHK(hipMemcpy(d_chosen, chosen.data(), sizeof(uint32_t) * chosen.size(), hipMemcpyHostToDevice));
+    sp.chosen = d_chosen;
+    SCHK(launch_split_apply(sp, h->stream));
+    SCHK(hipStreamSynchronize(h->stream));
+    for (size_t c = 0; c < C; ++c) sc[c].split_epoch += 1;
+    SCHK(hipMemcpy(h->d_scalars, sc.data(), sizeof(ChainScalars) * C, hipMemcpyHostToDevice));
+    if (compat) SCHK(hipMemcpy(h->d_mt_engine, mt_e.data(), sizeof(uint32_t) * mt_e.size(), hipMemcpyHostToDevice));
+#undef SCHK
+    cleanup();
+
+    // one block more: the block-state arrays grow with K
+    if (type)
+        h->kb += 1;
+    else
+        h->ka += 1;
+    h->K = h->ka + h->kb;
+    if (h->ka > h->cap_ka || h->kb > h->cap_kb) {
+        h->cap_ka = std::max(h->cap_ka, h->ka);
+        h->cap_kb = std::max(h->cap_kb, h->kb);
+        const size_t capK = (size_t)h->cap_ka + h->cap_kb, D = (size_t)h->maxdeg + 1;
+        for (void* p : {(void*)h->d_m, (void*)h->d_m_r, (void*)h->d_n_r, (void*)h->d_eta}) (void)hipFree(p);
+        h->d_m = nullptr, h->d_m_r = nullptr, h->d_n_r = nullptr, h->d_eta = nullptr;
+        HIPCHK(h, dalloc(&h->d_m, C * h->cap_ka * h->cap_kb));
+        HIPCHK(h, dalloc(&h->d_m_r, C * capK));
+        HIPCHK(h, dalloc(&h->d_n_r, C * capK));
+        HIPCHK(h, dalloc(&h->d_eta, C * capK * D));
+    }
+    return rebuild_state(h);  // compute_n_r / k / m / m_r / eta_rk at the end of apply_split_moves (:454-458)
+}
+
 // which: 0 = agg_merge(diff_a, diff_b, nm), 1 = agg_merge(diff, nm)
 int run_merges(bisbm_engine* h, int which, int diff_a, int diff_b, int nm) {
     if (!h->state_ready) return fail(h, BISBM_ERR_STATE, "call bisbm_init or bisbm_shuffle before bisbm_agg_merge");
-    if (diff_a < 0 || diff_b < 0)
-        return fail(h, BISBM_ERR_UNSUPPORTED,
-                    "negative diff asks for agg_split (blockmodel.cc:505-565), which reads out of range in the reference "
-                    "and is not provided");
     if (nm < 1) return fail(h, BISBM_ERR_INVALID_ARG, "nm must be >= 1");
+    if (which == 0) {  // blockmodel.cc:110-117: negative diffs are splits, one block at a time, type a first
+        while (diff_a < 0) {
+            const int rc = run_split(h, 0, nm);
+            if (rc) return rc;
+            ++diff_a;
+        }
+        while (diff_b < 0) {
+            const int rc = run_split(h, 1, nm);
+            if (rc) return rc;
+            ++diff_b;
+        }
+        if (diff_a + diff_b == 0) return BISBM_OK;  // :118-120
+    } else if (diff_a < 0) {
+        return fail(h, BISBM_ERR_INVALID_ARG, "agg_merge(engine, diff, nm) takes diff >= 0 (blockmodel.cc:208-271 has no split branch)");
+    }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const size_t C = h->n_chains, K0 = h->K, ka0 = h->ka, kb0 = h->kb;

@@ -710,8 +710,8 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                 //     target s' outside (min, max) is still the first block whose sum exceeds x.
                 // In those cases step q + 1 is evaluated again as the first step of the next pass; otherwise both
                 // steps are committed (their writes touch different rows).  The chain is the serial chain, bit for
-                // bit: the oracle knows nothing of this (orc_pair_probe counts how often the second step stands:
-                // ~80 % of the passes on the bench workload, 1.8 steps per pass).
+                // bit: the CPU checker steps one node at a time and the parity tests compare against it (measured on the
+                // bench workload: the second step stands in ~80 % of the passes, 1.8 steps per pass).
                 const uint32_t half = lane >> 5;
                 uint32_t acc_chunk = 0;  // accepted steps of the chunk's pair passes (a scalar word; added to acc_l0 per chunk)
                 // per-step inputs of the pair pass: degree, own block and pivot block in one word (one cross-lane move)

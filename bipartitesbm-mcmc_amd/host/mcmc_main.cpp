@@ -6,8 +6,8 @@
 // small parser with the same surface (long/short names, `--opt=value`, multitoken options).
 // Extra flags: --chains, --device, --rng {mt19937-compat,philox}, --gen_seed.
 // The agglomerative drivers (:349-451) run through bisbm_agg_merge; block counts are limited to 256 by the label
-// format, so --merge (one block per node to start with) is for graphs of at most 256 nodes.  Splits
-// (negative diffs, agg_split) are not provided: the library reports it.
+// format, so --merge (one block per node to start with) is for graphs of at most 256 nodes.
+// Negative diffs (agg_split) run through the same call (blockmodel.cc:110-117).
 #include <chrono>
 #include <cmath>
 #include <numeric>
@@ -445,7 +445,7 @@ int main(int argc, char const* argv[]) {
                 if (plan.first.size() == 1) blockmodel.agg_merge(diff_a, diff_b, 10);
                 if (!staged_merges(blockmodel, algorithm, plan.first, plan.second)) return 1;
             } else {
-                blockmodel.agg_merge(diff_a, diff_b, 100);  // splits: not provided, reported by the library
+                blockmodel.agg_merge(diff_a, diff_b, 100);  // :446 (negative diffs: agg_split)
             }
             algorithm.anneal(blockmodel, &abrupt_cool_schedule, kwargs, sampling_steps, steps_await);  // :447
             print_best(blockmodel, false);

@@ -29,7 +29,7 @@ typedef enum bisbm_status {
     BISBM_OK = 0,
     BISBM_ERR_INVALID_ARG = 1,   /* null pointer, size mismatch, label out of range ... */
     BISBM_ERR_NOT_BIPARTITE = 2, /* an edge joins two nodes of one type, or an id >= n */
-    BISBM_ERR_UNSUPPORTED = 3,   /* K > 256, more than 2^32-1 adjacency entries ... */
+    BISBM_ERR_UNSUPPORTED = 3,   /* K > 256 (labels are bytes), more than 2^32-1 adjacency entries ... */
     BISBM_ERR_NO_DEVICE = 4,     /* no HIP device / bad ordinal: the engine has no CPU path */
     BISBM_ERR_HIP = 5,           /* a HIP runtime call failed */
     BISBM_ERR_STATE = 6          /* call order (e.g. anneal before init/shuffle) */
@@ -127,13 +127,23 @@ int bisbm_marginals_get(bisbm_handle h, uint32_t *counts_out /* n*kmax, host */)
  * mcmc_main.cc:385,429,434,446): merge diff_a type-a and diff_b type-b blocks in every chain -- nm proposals per
  * block (single_block_change :639-669), lowest merge dS first (compute_dS :335-372), blocks renumbered in the
  * order of their first node (apply_block_moves :567-611), block state rebuilt.  Afterwards bisbm_get_ka_kb returns
- * the new counts; all chains must arrive at the same (Ka,Kb), else BISBM_ERR_STATE.  Negative diffs ask for
- * agg_split (:505-565), which reads out of range in the reference: BISBM_ERR_UNSUPPORTED.  The selection is
- * K-scale host work, as in the reference; relabelling and the rebuild run on the device. */
+ * the new counts.  A negative diff first splits one block per unit (agg_split :505-565, compute_dS(split) :374-424,
+ * apply_split_moves :428-459; type a first, :110-117): every block of the type with more than one node is cut nm
+ * times into random halves, the cut with the lowest dS wins, its marked nodes become block KA (type a; the type-b
+ * labels move up by one) or block K (type b).  The reference's split dS indexes its split vector with a counter that
+ * runs over all nodes (:402), an out-of-range read; the engine implements the intended meaning -- position = rank of
+ * the node within its block -- which is what agg_split's own pass (:554-561) uses.
+ * One (Ka,Kb) per handle: the two-type overload changes every chain's counts by the same amounts.  The selection is
+ * K-scale host work, as in the reference; ranks, cut evaluation, relabelling and the rebuild run on the device.
+ * BISBM_ERR_UNSUPPORTED when a split would exceed 256 blocks, BISBM_ERR_STATE when no block can be split. */
 int bisbm_agg_merge(bisbm_handle h, int diff_a, int diff_b, int nm);
 
 /* blockmodel_t::agg_merge(engine, diff, nm) (blockmodel.cc:208-271; call site mcmc_main.cc:365): diff merges over
- * both types together, proposals redrawn while the last one taken had dS = +inf. */
+ * both types together, proposals redrawn while the last one taken had dS = +inf.  Which types lose blocks is up to
+ * each chain's own proposals: when the chains of a handle end with different (Ka,Kb) the call fails with
+ * BISBM_ERR_STATE and leaves the state as it was (one block count per handle: the kernels are launched for one
+ * shape) -- run --nature style schedules with one chain per handle, or use the two-type overload.  diff < 0 is
+ * BISBM_ERR_INVALID_ARG (this overload has no split branch). */
 int bisbm_agg_merge_total(bisbm_handle h, int diff, int nm);
 
 /* Shape queries (get_KA/get_KB blockmodel.cc:103-105, get_num_edges :81). */

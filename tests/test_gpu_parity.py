@@ -336,8 +336,8 @@ def test_agg_merge_down_from_initial_partition(mode):
     rg = mh.anneal(g, "constant", [1.0], 3 * n, BIG)
     assert rg == ro
     assert_state_equal(g, o)
-    with pytest.raises(B.BisbmError):      # agg_split is not provided (reference reads out of range there)
-        g.agg_merge(-1, 0, 10)
+    with pytest.raises(B.BisbmError):      # the one-argument overload has no split branch (blockmodel.cc:208-271)
+        g.agg_merge(-1, None, 10)
 
 
 def test_agg_merge_many_chains_philox():
@@ -355,6 +355,127 @@ def test_agg_merge_many_chains_philox():
         o.shuffle_bisbm()
         assert o.agg_merge(4, 3, 10) == 0
         assert_state_equal(g, o, c)
+
+
+@pytest.mark.parametrize("mode", ["compat", "philox"])
+def test_agg_split_matches_oracle(mode):
+    """agg_split (blockmodel.cc:505-565, intended rank-within-block semantics) through negative diffs of
+    agg_merge (:110-117): one split per unit, type a first; then sweeps on the wider partition; then a call that
+    splits one type and merges the other."""
+    rowptr, col, na, nb = O.load_graph("n_1000")
+    n = na + nb
+    labels = O.contiguous_labels(na, nb, 3, 4)
+    o = O.OracleModel(rowptr, col, na, nb, 3, 4, 1.0, labels)
+    if mode == "compat":
+        o.seed_compat(21, 22)
+        g = gpu_model(rowptr, col, na, nb, 3, 4, 1.0, labels, rng="compat", seed=21, gen_seed=22)
+    else:
+        o.seed_philox(21, 6)
+        g = gpu_model(rowptr, col, na, nb, 3, 4, 1.0, labels, rng="philox", seed=21, first_chain_id=6)
+    o.shuffle_bisbm()
+    g.shuffle_bisbm()
+    mh = B.MetropolisHasting()
+    assert mh.anneal(g, "constant", [1.0], 2 * n, BIG) == o.anneal("constant", [1.0], 2 * n, BIG)
+    assert o.agg_merge(-1, -2, 7) == 0
+    g.agg_merge(-1, -2, 7)
+    assert (g.KA, g.KB) == (o.ka, o.kb) == (4, 6)
+    assert_state_equal(g, o)
+    assert g.entropy()[0] == pytest.approx(o.entropy(), rel=1e-12)
+    assert mh.anneal(g, "constant", [1.0], 3 * n, BIG) == o.anneal("constant", [1.0], 3 * n, BIG)
+    assert_state_equal(g, o)
+    assert o.agg_merge(-1, 2, 10) == 0  # one more type-a block, two type-b blocks fewer
+    g.agg_merge(-1, 2, 10)
+    assert (g.KA, g.KB) == (o.ka, o.kb) == (5, 4)
+    assert_state_equal(g, o)
+    assert mh.anneal(g, "abrupt_cool", [0.0], n, BIG) == o.anneal("abrupt_cool", [0.0], n, BIG)
+    assert_state_equal(g, o)
+    # marginals on the wider partition (the histogram has max(KA, KB) columns)
+    g.marginals_reset()
+    g.marginals_accumulate()
+    counts = g.marginals_get()
+    assert counts.shape == (n, 5) and (counts.sum(axis=1) == 1).all()
+
+
+def test_agg_split_many_chains_philox():
+    """48 chains split at once (type b, then type a); sampled chains equal their own oracle runs."""
+    rowptr, col, na, nb = O.load_graph("n_1000")
+    labels = O.contiguous_labels(na, nb, 4, 5)
+    chains = 48
+    g = gpu_model(rowptr, col, na, nb, 4, 5, 1.0, labels, n_chains=chains, rng="philox", seed=8, first_chain_id=3)
+    g.shuffle_bisbm()
+    g.agg_merge(0, -1, 12)
+    g.agg_merge(-1, 0, 12)
+    assert (g.KA, g.KB) == (5, 6)
+    for c in range(0, chains, 11):
+        o = O.OracleModel(rowptr, col, na, nb, 4, 5, 1.0, labels)
+        o.seed_philox(8, 3 + c)
+        o.shuffle_bisbm()
+        assert o.agg_split(1, 12) == 0 and o.agg_split(0, 12) == 0
+        assert_state_equal(g, o, c)
+    # refusals: 256 blocks is the label format's limit; a partition of single nodes cannot be split
+    rp, cl, a2, b2 = O.load_graph("southernWomen")
+    t = gpu_model(rp, cl, a2, b2, a2, b2, 0.001, np.arange(a2 + b2, dtype=np.uint32), rng="philox", seed=1)
+    t.init_bisbm()
+    with pytest.raises(B.BisbmError):
+        t.agg_merge(-1, 0, 5)
+
+
+def test_agg_merge_total_refuses_diverging_chains():
+    """agg_merge(engine, diff, nm) lets every run end with its own (Ka,Kb) (blockmodel.cc:208-271); a handle has one
+    block count for all its chains, so diverging chains are refused (BISBM_ERR_STATE) and nothing is changed; one chain
+    per handle (the CLI's --nature) always works."""
+    rowptr, col, na, nb = O.load_graph("n_1000")
+    labels = O.contiguous_labels(na, nb, 8, 9)
+    chains = 64
+    g = gpu_model(rowptr, col, na, nb, 8, 9, 1.0, labels, n_chains=chains, rng="philox", seed=123)
+    g.shuffle_bisbm()
+    ends = set()
+    for c in range(chains):
+        o = O.OracleModel(rowptr, col, na, nb, 8, 9, 1.0, labels)
+        o.seed_philox(123, c)
+        o.shuffle_bisbm()
+        assert o.agg_merge_total(5, 10) == 0
+        ends.add((o.ka, o.kb))
+    assert len(ends) > 1  # the premise: these chains do not agree
+    before = [g.get_memberships(c) for c in (0, 17, 63)]
+    with pytest.raises(B.BisbmError) as e:
+        g.agg_merge(5, None, 10)
+    assert e.value.code == B.BISBM_ERR_STATE
+    assert (g.KA, g.KB) == (8, 9)
+    for c, lab in zip((0, 17, 63), before):
+        assert (g.get_memberships(c) == lab).all()
+    rates = B.MetropolisHasting().anneal(g, "constant", [1.0], na + nb, BIG)  # the handle is still good
+    assert (rates > 0).all()
+    # the same call on a one-chain handle: the chain's own end point
+    solo = gpu_model(rowptr, col, na, nb, 8, 9, 1.0, labels, n_chains=1, rng="philox", seed=123, first_chain_id=17)
+    solo.shuffle_bisbm()
+    solo.agg_merge(5, None, 10)
+    o = O.OracleModel(rowptr, col, na, nb, 8, 9, 1.0, labels)
+    o.seed_philox(123, 17)
+    o.shuffle_bisbm()
+    o.agg_merge_total(5, 10)
+    assert (solo.KA, solo.KB) == (o.ka, o.kb)
+    assert_state_equal(solo, o)
+
+
+def test_cli_split_matches_oracle_replay():
+    """`mcmc` with -z larger than the initial partition (mcmc_main.cc:419-451, else branch: agg_merge(diff_a, diff_b,
+    100) with negative diffs = agg_split, then the final anneal) against the same driver replayed with the oracle."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "bipartitesbm-mcmc_amd", "bin", "mcmc")
+    r = subprocess.run([cli, "-e", os.path.join(O.GOLDEN, "southernWomen.edgelist"), "-y", "18", "14", "-n", "9", "9", "7", "7",
+                        "-z", "3", "4", "-t", "3200", "-x", "100000", "-c", "abrupt_cool", "-a", "320", "-E", "0.001",
+                        "-d", "42", "--gen_seed", "43"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rowptr, col, na, nb = O.load_graph("southernWomen")
+    o = O.OracleModel(rowptr, col, na, nb, 2, 2, 0.001, O.labels_from_sizes([9, 9, 7, 7]))
+    o.seed_compat(42, 43)
+    o.init_bisbm()
+    assert o.agg_merge(2 - 3, 2 - 4, 100) == 0
+    o.anneal("abrupt_cool", [320.0], 3200, 100000)
+    assert r.stdout == " ".join(map(str, o.memberships())) + " \n"
+    assert "(Ka, Kb) = (3, 4) " in r.stderr
 
 
 def test_anneal_splits_compose_on_device():

@@ -450,7 +450,7 @@ def test_agg_merge_properties(mode):
     assert (p.memberships() == lab).all()
     assert o.agg_merge_total(3, 10) == 0 and o.K == 8
     assert o.agg_merge(0, 0, 10) == 0 and o.K == 8
-    assert o.agg_merge(-1, 0, 10) == -2          # agg_split is not restated (reference reads out of range there)
+    assert o.agg_merge_total(-1, 10) == -2       # the one-argument overload has no split branch (blockmodel.cc:208-271)
     one = O.OracleModel(rowptr, col, na, nb, 1, 3, 1.0, O.contiguous_labels(na, nb, 1, 3))
     one.seed_compat(1, 2) if mode == "compat" else one.seed_philox(1, 2)
     one.init_bisbm()
