@@ -73,6 +73,8 @@ ABI = {
     "bisbm_io_read_edge_list": (C.c_long, [C.c_char_p, C.POINTER(_u64p), C.POINTER(_u64p)]),
     "bisbm_io_read_memberships": (C.c_long, [C.c_char_p, C.POINTER(_u32p)]),
     "bisbm_io_edges_to_csr": (C.c_int, [_u64p, _u64p, C.c_size_t, C.c_uint64, _u64p, _u32p]),
+    "bisbm_io_load_csr": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int, C.POINTER(_u64p), C.POINTER(_u32p), _u64p,
+                                    C.POINTER(C.c_int)]),
     "bisbm_io_format_labels": (C.c_size_t, [_u32p, C.c_size_t, C.c_char_p, C.c_size_t]),
     "bisbm_io_free": (None, [C.c_void_p]),
 }
@@ -187,6 +189,27 @@ def edge_to_adj(edge_list, num_vertices):
     return rowptr, col[: 2 * len(a)]
 
 
+def load_graph(path, num_vertices, cache=False):
+    """load_edge_list + edge_to_adj (graph_utilities.cc:20-49) in one call -> (rowptr, col).  cache=True keeps a binary
+    CSR beside the text file (`<path>.bisbm_csr`, validated against the file's size and mtime and rebuilt when they
+    change); the text format stays the source of truth.  `load_graph.last_cache_hit` tells where the arrays came from."""
+    L = lib()
+    rp, cl = _u64p(), _u32p()
+    ne, hit = C.c_uint64(), C.c_int()
+    rc = L.bisbm_io_load_csr(os.fsencode(path), int(num_vertices), int(bool(cache)), C.byref(rp), C.byref(cl), C.byref(ne),
+                             C.byref(hit))
+    if rc == -1:
+        raise FileNotFoundError(path)
+    if rc != 0:
+        raise ValueError("edge list has a node id >= %d" % num_vertices)
+    rowptr = np.ctypeslib.as_array(rp, shape=(num_vertices + 1,)).copy()
+    col = np.ctypeslib.as_array(cl, shape=(max(2 * ne.value, 1),))[: 2 * ne.value].copy()
+    L.bisbm_io_free(rp)
+    L.bisbm_io_free(cl)
+    load_graph.last_cache_hit = bool(hit.value)
+    return rowptr, col
+
+
 def output_vec(vec, stream=None):
     """output_functions.hh:20-29: elements separated by blanks, trailing blank, newline."""
     L = lib()
@@ -224,10 +247,21 @@ class BlockModel:
         self.K = self.KA + self.KB
         self.epsilon = float(epsilon)
         self.n_chains = int(n_chains)
+        self.device = int(device)
         rowptr = np.ascontiguousarray(adj[0], dtype=np.uint64)
         col = np.ascontiguousarray(adj[1], dtype=np.uint32)
         if len(rowptr) != self.n + 1:
             raise ValueError("adjacency has %d rows, types has %d nodes" % (len(rowptr) - 1, self.n))
+        # A process that also uses torch.cuda (pooled marginals: a torch device tensor is handed to the library) must let
+        # torch bring the device up first: its wheel carries its own HIP runtime, and the other order leaves torch
+        # without a GPU.  Only done when the caller has imported torch already.
+        _torch = sys.modules.get("torch")
+        if _torch is not None:
+            try:
+                if _torch.cuda.is_available():
+                    _torch.cuda.init()
+            except Exception:
+                pass
         h = C.c_void_p()
         rc = L.bisbm_create(C.byref(h), self.n, self.na, self.nb, _p(rowptr, _u64p), _p(col, _u32p), self.KA,
                             self.KB, self.epsilon, self.n_chains, int(first_chain_id), int(device),
@@ -365,10 +399,21 @@ class BlockModel:
     def kmax(self):
         return max(self.KA, self.KB)
 
+    def run_sweeps(self, sweeps, temperature=1.0):
+        """`sweeps` sweeps at constant temperature (the "marginalize" regime: -c constant -a 1)."""
+        return MetropolisHasting().anneal(self, constant_schedule, [temperature], int(sweeps) * self.n, 1 << 60)
+
+    def counts_device(self):
+        """torch device a caller-owned marginal histogram must live on."""
+        import torch
+        return torch.device("cuda", self.device)
+
     def marginals_reset(self):
         self._check(self._L.bisbm_marginals_reset(self._h))
 
     def marginals_accumulate(self, device_ptr=None):
+        """One sample of every chain's labels into the internal histogram (device_ptr None) or ADDED to the caller's
+        device buffer of n * kmax uint32 / int32 at `device_ptr` (e.g. torch_tensor.data_ptr())."""
         self._check(self._L.bisbm_marginals_accumulate(self._h, C.c_void_p(device_ptr) if device_ptr else None))
 
     def marginals_get(self):

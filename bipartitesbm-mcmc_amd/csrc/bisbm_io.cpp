@@ -6,6 +6,9 @@
 #include <string>
 #include <vector>
 
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "../../include/bisbm_io.h"
 
 namespace {
@@ -139,6 +142,90 @@ int bisbm_io_edges_to_csr(const uint64_t* a, const uint64_t* b, size_t n_edges, 
     for (size_t e = 0; e < n_edges; ++e) {  // push_back(b) on row a, then push_back(a) on row b (:45-46)
         col[cursor[a[e]]++] = (uint32_t)b[e];
         col[cursor[b[e]]++] = (uint32_t)a[e];
+    }
+    return 0;
+}
+
+namespace {
+struct CsrCacheHeader {
+    char magic[8];
+    uint32_t version, reserved;
+    uint64_t src_size;
+    int64_t src_mtime_ns;
+    uint64_t n, n_edges;
+};
+static_assert(sizeof(CsrCacheHeader) == 48, "cache header layout");
+constexpr char kCsrMagic[8] = {'B', 'I', 'S', 'B', 'M', 'C', 'S', 'R'};
+}  // namespace
+
+int bisbm_io_load_csr(const char* path, uint64_t n, int use_cache, uint64_t** rowptr, uint32_t** col, uint64_t* n_edges,
+                      int* cache_hit) {
+    if (cache_hit) *cache_hit = 0;
+    *rowptr = nullptr;
+    *col = nullptr;
+    struct stat st;
+    if (stat(path, &st) != 0) return -1;
+    const std::string cpath = std::string(path) + ".bisbm_csr";
+    const int64_t mtime_ns = (int64_t)st.st_mtim.tv_sec * 1000000000ll + (int64_t)st.st_mtim.tv_nsec;
+    if (use_cache) {
+        if (FILE* f = std::fopen(cpath.c_str(), "rb")) {
+            CsrCacheHeader h;
+            struct stat cs;
+            bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, kCsrMagic, 8) == 0 && h.version == 1 &&
+                      h.src_size == (uint64_t)st.st_size && h.src_mtime_ns == mtime_ns && h.n == n && fstat(fileno(f), &cs) == 0 &&
+                      (uint64_t)cs.st_size == sizeof(h) + sizeof(uint64_t) * (n + 1) + sizeof(uint32_t) * 2 * h.n_edges;
+            if (ok) {
+                uint64_t* rp = (uint64_t*)std::malloc(sizeof(uint64_t) * (n + 1));
+                uint32_t* cl = (uint32_t*)std::malloc(sizeof(uint32_t) * (2 * h.n_edges + 1));
+                ok = rp && cl && std::fread(rp, sizeof(uint64_t), n + 1, f) == n + 1 &&
+                     (h.n_edges == 0 || std::fread(cl, sizeof(uint32_t), 2 * h.n_edges, f) == 2 * h.n_edges) && rp[0] == 0 &&
+                     rp[n] == 2 * h.n_edges;
+                if (ok) {
+                    std::fclose(f);
+                    *rowptr = rp;
+                    *col = cl;
+                    *n_edges = h.n_edges;
+                    if (cache_hit) *cache_hit = 1;
+                    return 0;
+                }
+                std::free(rp);
+                std::free(cl);
+            }
+            std::fclose(f);
+        }
+    }
+    uint64_t *a = nullptr, *b = nullptr;
+    const long ne = bisbm_io_read_edge_list(path, &a, &b);
+    if (ne < 0) return -1;
+    uint64_t* rp = (uint64_t*)std::malloc(sizeof(uint64_t) * (n + 1));
+    uint32_t* cl = (uint32_t*)std::malloc(sizeof(uint32_t) * (2 * (size_t)ne + 1));
+    const int rc = bisbm_io_edges_to_csr(a, b, (size_t)ne, n, rp, cl);
+    std::free(a);
+    std::free(b);
+    if (rc != 0) {
+        std::free(rp);
+        std::free(cl);
+        return -2;
+    }
+    *rowptr = rp;
+    *col = cl;
+    *n_edges = (uint64_t)ne;
+    if (use_cache) {  // best effort: a read-only directory just means no cache
+        const std::string tmp = cpath + ".tmp." + std::to_string((long)getpid());
+        if (FILE* f = std::fopen(tmp.c_str(), "wb")) {
+            CsrCacheHeader h;
+            std::memcpy(h.magic, kCsrMagic, 8);
+            h.version = 1;
+            h.reserved = 0;
+            h.src_size = (uint64_t)st.st_size;
+            h.src_mtime_ns = mtime_ns;
+            h.n = n;
+            h.n_edges = (uint64_t)ne;
+            const bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && std::fwrite(rp, sizeof(uint64_t), n + 1, f) == n + 1 &&
+                            (ne == 0 || std::fwrite(cl, sizeof(uint32_t), 2 * (size_t)ne, f) == 2 * (size_t)ne);
+            const bool closed = std::fclose(f) == 0;
+            if (!(ok && closed && std::rename(tmp.c_str(), cpath.c_str()) == 0)) std::remove(tmp.c_str());
+        }
     }
     return 0;
 }

@@ -76,6 +76,21 @@ inline adj_list_t edge_to_adj(const edge_list_t& edge_list, size_t num_vertices 
     return adj;
 }
 
+// load_edge_list + edge_to_adj with the optional binary CSR cache of include/bisbm_io.h (num_vertices as in edge_to_adj)
+inline bool load_adj_cached(adj_list_t& adj, const std::string& path, size_t num_vertices, bool use_cache, bool* hit = nullptr) {
+    uint64_t* rp = nullptr;
+    uint32_t* cl = nullptr;
+    uint64_t ne = 0;
+    int h = 0;
+    if (bisbm_io_load_csr(path.c_str(), num_vertices, use_cache ? 1 : 0, &rp, &cl, &ne, &h) != 0) return false;
+    adj.rowptr.assign(rp, rp + num_vertices + 1);
+    adj.col.assign(cl, cl + 2 * ne);
+    bisbm_io_free(rp);
+    bisbm_io_free(cl);
+    if (hit) *hit = h != 0;
+    return true;
+}
+
 // ---- output_functions.hh:20-29 ----
 template <typename T>
 void output_vec(const T& vec, std::ostream& stream = std::clog) {

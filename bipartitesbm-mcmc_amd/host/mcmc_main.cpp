@@ -4,7 +4,7 @@
 // partition rules (:241-326), same stdout contract: the label vector through output_vec (trailing blank,
 // newline), "acceptance ratio" and summary() on clog (:483-485).  Boost.program_options is replaced by a
 // small parser with the same surface (long/short names, `--opt=value`, multitoken options).
-// Extra flags: --chains, --device, --rng {mt19937-compat,philox}, --gen_seed.
+// Extra flags: --chains, --device, --rng {mt19937-compat,philox}, --gen_seed, --csr_cache.
 // The agglomerative drivers (:349-451) run through bisbm_agg_merge; block counts are limited to 256 by the label
 // format, so --merge (one block per node to start with) is for graphs of at most 256 nodes.
 // Negative diffs (agg_split) run through the same call (blockmodel.cc:110-117).
@@ -41,6 +41,7 @@ const option_spec kOptions[] = {
     {"seed", 'd', 1},           {"help", 'h', 0},
     // engine extras
     {"chains", 0, 1},           {"device", 0, 1},          {"rng", 0, 1},          {"gen_seed", 0, 1},
+    {"csr_cache", 0, 0},
 };
 
 const option_spec* find_long(const std::string& name) {
@@ -153,7 +154,9 @@ void print_help(const char* argv0) {
                  "                                        description length are printed.\n"
                  "  --device arg (=0)                     HIP device ordinal.\n"
                  "  --rng arg (=mt19937-compat)           mt19937-compat (the reference's draw sequence) or philox.\n"
-                 "  --gen_seed arg (=seed+1)              Seed of the reference's hidden second engine (blockmodel.hh:18).\n";
+                 "  --gen_seed arg (=seed+1)              Seed of the reference's hidden second engine (blockmodel.hh:18).\n"
+                 "  --csr_cache                           Keep a binary CSR beside the edge list (<path>.bisbm_csr, checked\n"
+                 "                                        against the file's size and mtime); the text file stays the input.\n";
 }
 
 }  // namespace
@@ -345,10 +348,18 @@ int main(int argc, char const* argv[]) {
     }
 
     // ---- graph, mcmc_main.cc:335-339 ----
-    edge_list_t edge_list;
-    load_edge_list(edge_list, single("edge_list_path", ""));
-    const adj_list_t adj_list = edge_to_adj(edge_list, N);
-    edge_list.clear();
+    adj_list_t adj_list_loaded;
+    if (count("csr_cache")) {  // same arrays as the two calls below, kept in a binary file beside the text
+        if (!load_adj_cached(adj_list_loaded, single("edge_list_path", ""), N, true)) {
+            std::cerr << "[error] cannot read the edge list, or it names a node id >= " << N << "\n";
+            return 1;
+        }
+    } else {
+        edge_list_t edge_list;
+        load_edge_list(edge_list, single("edge_list_path", ""));
+        adj_list_loaded = edge_to_adj(edge_list, N);
+    }
+    const adj_list_t& adj_list = adj_list_loaded;
 
     // K implied by the initial labels vs. requested (mcmc_main.cc:406-419)
     size_t ka = 0, kb = 0;

@@ -5,40 +5,63 @@
 Semantics (the README prose is the only specification): constant temperature T = 1; `burn_in` sweeps are
 discarded; then `n_samples` samples are taken `sampling_frequency` sweeps apart; a sample adds every chain's
 label of every node to a per-node histogram; the marginal estimate of a node is its most frequent block
-(ties -> lowest block index).  With several ranks the histograms are pooled with the collectives of
-`distributed.ChainShard`.
+(ties -> lowest block index).
+
+Pooling over ranks stays on the device: every rank's chains are histogrammed by the marginals kernel
+straight into a torch tensor on the rank's GPU (`bisbm_marginals_accumulate(device_counts)`), that tensor is
+reduce-scattered by node range (`ChainShard.map_labels`: RCCL over xGMI with the nccl backend), each rank takes the
+argmax of its rows, and the uint8 labels are all-gathered -- no host copy of the n x kmax histogram anywhere.  (With
+the gloo backend of the CPU tests the same tensor is moved to the host first: gloo reduces host tensors.)
 """
 import numpy as np
 
 
-def marginalize(model, burn_in_sweeps, n_samples, sampling_frequency_sweeps, shard=None, device_counts=None):
+def marginalize(model, burn_in_sweeps, n_samples, sampling_frequency_sweeps, shard=None, device_counts=None,
+                return_counts=True):
     """Runs the chain(s) of `model` (a BlockModel whose state is already initialised by init_bisbm() /
     shuffle_bisbm()) and returns (labels, counts):
-      labels  uint8/uint32 [n]  MAP block of every node in the reference's numbering
-      counts  [n, max(KA,KB)]   pooled histogram (column = block index within the node's type)
-    `shard`: a distributed.ChainShard when chains are spread over ranks (pooling by RCCL / gloo)."""
-    from . import MetropolisHasting, constant_schedule
-    mh = MetropolisHasting()
+      labels  uint32 [n]         MAP block of every node in the reference's numbering
+      counts  [n, max(KA,KB)]    pooled histogram (column = block index within the node's type); None when
+                                 return_counts is False (with several ranks the pooled histogram costs an all_reduce)
+    `shard`: a distributed.ChainShard when chains are spread over ranks.
+    `device_counts`: a torch int32 tensor [n, kmax] on the model's device to accumulate into (it is NOT zeroed: samples
+    add to what it holds); by default one is allocated when pooling over ranks, and the library's internal buffer is
+    used for a single rank."""
     n = model.n
-    big = 1 << 60
     if burn_in_sweeps > 0:
-        mh.anneal(model, constant_schedule, [1.0], burn_in_sweeps * n, big)
-    model.marginals_reset()
+        model.run_sweeps(burn_in_sweeps)
+    multi = shard is not None and shard.world_size > 1
+    if device_counts is None and not multi:
+        # one rank, no caller buffer: the library's own histogram
+        model.marginals_reset()
+        for _ in range(int(n_samples)):
+            if sampling_frequency_sweeps > 0:
+                model.run_sweeps(sampling_frequency_sweeps)
+            model.marginals_accumulate(None)
+        counts = model.marginals_get().astype(np.int64)
+        base = np.where(np.arange(n) >= model.na, model.KA, 0)
+        return (counts.argmax(axis=1) + base).astype(np.uint32), (counts if return_counts else None)
+
+    import torch
+    if device_counts is None:
+        device_counts = torch.zeros((n, model.kmax), dtype=torch.int32, device=model.counts_device())
+    if (not isinstance(device_counts, torch.Tensor) or device_counts.dtype != torch.int32
+            or tuple(device_counts.shape) != (n, model.kmax) or not device_counts.is_contiguous()):
+        raise ValueError("device_counts must be a contiguous torch.int32 tensor of shape (n, max(KA, KB)) on the model's device")
     for _ in range(int(n_samples)):
         if sampling_frequency_sweeps > 0:
-            mh.anneal(model, constant_schedule, [1.0], sampling_frequency_sweeps * n, big)
-        model.marginals_accumulate(device_counts)
-    counts = model.marginals_get().astype(np.int64)
-    if shard is not None and shard.world_size > 1:
-        import torch
-        t = torch.from_numpy(counts.astype(np.int32))
-        if device_counts is not None or _uses_cuda_backend(shard):
-            t = t.cuda()
-        pooled = shard.pooled_marginals(t)
-        labels = shard.map_labels(t, model.na, model.KA).cpu().numpy()
-        return labels, pooled.cpu().numpy().astype(np.int64)
-    base = np.where(np.arange(n) >= model.na, model.KA, 0)
-    return (counts.argmax(axis=1) + base).astype(np.uint32), counts
+            model.run_sweeps(sampling_frequency_sweeps)
+        model.marginals_accumulate(device_counts.data_ptr())  # adds into the tensor, on the device
+    if not multi:
+        from .distributed import _argmax_first
+        arg = _argmax_first(device_counts)
+        node = torch.arange(n, device=device_counts.device)
+        labels = (arg + torch.where(node >= model.na, model.KA, 0)).cpu().numpy().astype(np.uint32)
+        return labels, (device_counts.cpu().numpy().astype(np.int64) if return_counts else None)
+    send = device_counts if _uses_cuda_backend(shard) else device_counts.cpu()
+    labels = shard.map_labels(send, model.na, model.KA).cpu().numpy().astype(np.uint32)
+    counts = shard.pooled_marginals(send).cpu().numpy().astype(np.int64) if return_counts else None
+    return labels, counts
 
 
 def _uses_cuda_backend(shard):

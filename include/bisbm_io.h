@@ -28,6 +28,18 @@ long bisbm_io_read_memberships(const char *path, uint32_t **labels);
 int bisbm_io_edges_to_csr(const uint64_t *a, const uint64_t *b, size_t n_edges, uint64_t n,
                           uint64_t *rowptr, uint32_t *col);
 
+/* load_edge_list + edge_to_adj in one call, with an optional binary cache beside the text file
+ * (1e7..5e7-line edge lists through a line parser are slow; the TEXT FORMAT IS UNTOUCHED and stays the
+ * source of truth).  The cache is `<path>.bisbm_csr`: a 48-byte header {magic "BISBMCSR", version, size and mtime
+ * (ns) of the text file, n, n_edges}, then rowptr (n+1 x u64) and col (2 n_edges x u32) exactly as
+ * bisbm_io_edges_to_csr builds them.  It is used only when size, mtime, n and the file's own length all match, and
+ * rewritten (temporary file + rename) otherwise; a directory that cannot be written to just means no cache.
+ * use_cache = 0: always parse the text, never touch a cache file.
+ * Returns 0 and malloc'ed arrays (bisbm_io_free), -1 when the text file cannot be opened, -2 when an id is >= n.
+ * *cache_hit (may be NULL) tells whether the arrays came from the cache. */
+int bisbm_io_load_csr(const char *path, uint64_t n, int use_cache, uint64_t **rowptr, uint32_t **col,
+                      uint64_t *n_edges, int *cache_hit);
+
 /* output_vec (output_functions.hh:20-29): every element followed by one blank, then '\n'.
  * Returns the length written (without the NUL); call with out == NULL to size the buffer. */
 size_t bisbm_io_format_labels(const uint32_t *labels, size_t n, char *out, size_t cap);

@@ -125,3 +125,58 @@ def test_cli_flag_handling_matches_reference_messages(built):
     rc, out, err = run("-e", el, "-y", "18", "14", "-n", "18", "14", "-z", "5", "5", "--merge", "-c", "abrupt_cool",
                        "-a", "50", "-t", "320")
     assert (rc == 3 and "no HIP device" in err and out == "") or (rc == 0 and len(out.split()) == 32)
+
+
+def test_csr_cache_round_trip(built, tmp_path):
+    """load_graph(cache=True): the binary CSR beside the text file equals what the text gives (quirky lines included),
+    is reused only while the text file's size and mtime match, is rebuilt after an edit or a corrupted cache, and a
+    run without the flag never creates it (graph_utilities.cc:20-49 stays the format)."""
+    import shutil
+    import time
+    p = tmp_path / "g.el"
+    p.write_text("0\t5\n1 6\n\n2   7\r\nabc def\n3\n4 8 junk\n  1\t9  \n")
+    n = 10
+    want = B.edge_to_adj(B.load_edge_list(str(p)), n)
+    r0 = B.load_graph(str(p), n)                       # no cache asked for
+    assert not os.path.exists(str(p) + ".bisbm_csr") and not B.load_graph.last_cache_hit
+    r1 = B.load_graph(str(p), n, cache=True)           # builds it
+    assert not B.load_graph.last_cache_hit and os.path.exists(str(p) + ".bisbm_csr")
+    r2 = B.load_graph(str(p), n, cache=True)           # uses it
+    assert B.load_graph.last_cache_hit
+    for r in (r0, r1, r2):
+        assert (r[0] == want[0]).all() and (r[1] == want[1]).all()
+    B.load_graph(str(p), n + 1, cache=True)            # another vertex count: not this cache
+    assert not B.load_graph.last_cache_hit
+    B.load_graph(str(p), n, cache=True)
+    assert not B.load_graph.last_cache_hit             # (the n + 1 run replaced the file)
+    assert B.load_graph(str(p), n, cache=True) and B.load_graph.last_cache_hit
+    # an edited text file invalidates the cache (size and mtime are part of the key)
+    time.sleep(0.01)
+    with open(p, "a") as f:
+        f.write("2 9\n")
+    r3 = B.load_graph(str(p), n, cache=True)
+    assert not B.load_graph.last_cache_hit
+    want3 = B.edge_to_adj(B.load_edge_list(str(p)), n)
+    assert (r3[0] == want3[0]).all() and (r3[1] == want3[1]).all() and len(r3[1]) == len(want[1]) + 2
+    # a truncated cache file is ignored and replaced
+    c = str(p) + ".bisbm_csr"
+    data = open(c, "rb").read()
+    open(c, "wb").write(data[:-4])
+    r4 = B.load_graph(str(p), n, cache=True)
+    assert not B.load_graph.last_cache_hit and (r4[1] == want3[1]).all()
+    assert open(c, "rb").read() == data
+    # errors
+    with pytest.raises(FileNotFoundError):
+        B.load_graph(str(tmp_path / "missing"), 3, cache=True)
+    with pytest.raises(ValueError):
+        B.load_graph(str(p), 5, cache=True)
+    # a directory that cannot be written to: no cache, same arrays
+    ro = tmp_path / "ro"
+    ro.mkdir()
+    shutil.copy(p, ro / "g.el")
+    os.chmod(ro, 0o555)
+    try:
+        r5 = B.load_graph(str(ro / "g.el"), n, cache=True)
+        assert (r5[1] == want3[1]).all()
+    finally:
+        os.chmod(ro, 0o755)

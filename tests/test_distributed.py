@@ -106,3 +106,70 @@ def test_single_process_paths():
     counts = torch.tensor([[1, 3, 3], [2, 0, 1], [0, 0, 4]], dtype=torch.int32)
     assert torch.equal(shard.pooled_marginals(counts), counts)
     assert shard.map_labels(counts, 2, 3).tolist() == [1, 0, 5]
+
+
+# ------------------------------------------------------------------ marginalize() end to end over two ranks
+class _OracleChains:
+    """Stands in for BlockModel in marginalize(): the rank's chains are oracle chains (Philox streams keyed by the global
+    chain id, like the GPU's), the histogram buffer is the caller's torch tensor, written through its data pointer
+    exactly as the HIP marginals kernel writes a device tensor."""
+
+    def __init__(self, first_chain, n_local):
+        rowptr, col, na, nb = O.load_graph("southernWomen")
+        self.n, self.na, self.KA, self.KB = na + nb, na, 5, 5
+        self.kmax = 5
+        self.chains = []
+        for c in range(n_local):
+            m = O.OracleModel(rowptr, col, na, nb, 5, 5, 0.001, O.contiguous_labels(na, nb, 5, 5))
+            m.seed_philox(31337, first_chain + c)
+            m.shuffle_bisbm()
+            self.chains.append(m)
+
+    def run_sweeps(self, sweeps, temperature=1.0):
+        for m in self.chains:
+            m.anneal("constant", [temperature], sweeps * self.n, 1 << 60)
+
+    def counts_device(self):
+        return torch.device("cpu")
+
+    def marginals_accumulate(self, ptr):
+        import ctypes
+        buf = np.ctypeslib.as_array((ctypes.c_int32 * (self.n * self.kmax)).from_address(ptr)).reshape(self.n, self.kmax)
+        buf += D.numpy_marginals(np.array([m.memberships() for m in self.chains]).reshape(-1, self.n), self.na, 5, 5)
+
+    def marginals_reset(self):
+        raise AssertionError("the pooled path must not use the library's internal histogram")
+
+    marginals_get = marginals_reset
+
+
+def _marg_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shard = D.ChainShard(TOTAL_CHAINS)
+        model = _OracleChains(shard.first_chain_id, shard.n_local)
+        labels, counts = B.marginalize(model, 2, 3, 1, shard=shard)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "m_labels.npy"), labels)
+            np.save(os.path.join(out_dir, "m_counts.npy"), counts)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_marginalize_end_to_end(tmp_path):
+    port = _free_port()
+    mp.spawn(_marg_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    labels = np.load(tmp_path / "m_labels.npy")
+    counts = np.load(tmp_path / "m_counts.npy")
+    # single process, all chains
+    solo = _OracleChains(0, TOTAL_CHAINS)
+    want_labels, want_counts = B.marginalize(solo, 2, 3, 1, device_counts=torch.zeros((32, 5), dtype=torch.int32))
+    assert (counts == want_counts).all() and counts.sum() == TOTAL_CHAINS * 32 * 3
+    assert (labels == want_labels).all()
+    base = np.where(np.arange(32) >= 18, 5, 0)
+    assert (labels == want_counts.argmax(axis=1) + base).all()
+    with pytest.raises(ValueError):  # a raw pointer or a wrongly shaped buffer is refused, not silently ignored
+        B.marginalize(solo, 0, 1, 1, device_counts=12345)

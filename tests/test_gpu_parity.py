@@ -266,6 +266,17 @@ def test_marginalize_driver_matches_oracle_samples():
     assert (counts == want).all() and counts.sum() == chains * samples * 32
     base = np.where(np.arange(32) >= na, 5, 0)
     assert (lab == want.argmax(axis=1) + base).all()
+    # the same run into a caller-owned device tensor (the buffer RCCL reduces when chains are spread over ranks):
+    # samples are ADDED to what the tensor holds, and the result is built from that tensor
+    import torch
+    g2 = gpu_model(rowptr, col, na, nb, 5, 5, 0.5, labels, n_chains=chains, rng="philox", seed=31)
+    g2.shuffle_bisbm()
+    dev = torch.full((na + nb, 5), 7, dtype=torch.int32, device=g2.counts_device())
+    lab2, counts2 = B.marginalize(g2, burn, samples, freq, device_counts=dev)
+    assert (counts2 == want + 7).all() and (dev.cpu().numpy() == want + 7).all()
+    assert (lab2 == want.argmax(axis=1) + base).all()
+    with pytest.raises(ValueError):
+        B.marginalize(g2, 0, 1, 1, device_counts=dev.data_ptr())  # a raw pointer is refused
 
 
 # ------------------------------------------------------------------ agglomerative merges
@@ -425,34 +436,40 @@ def test_agg_merge_total_refuses_diverging_chains():
     block count for all its chains, so diverging chains are refused (BISBM_ERR_STATE) and nothing is changed; one chain
     per handle (the CLI's --nature) always works."""
     rowptr, col, na, nb = O.load_graph("n_1000")
+    n = na + nb
     labels = O.contiguous_labels(na, nb, 8, 9)
-    chains = 64
+    chains = 32
     g = gpu_model(rowptr, col, na, nb, 8, 9, 1.0, labels, n_chains=chains, rng="philox", seed=123)
     g.shuffle_bisbm()
+    mh = B.MetropolisHasting()
+    mh.anneal(g, "constant", [1.0], 3 * n, BIG)  # (right after a shuffle every chain merges type b only)
     ends = set()
     for c in range(chains):
         o = O.OracleModel(rowptr, col, na, nb, 8, 9, 1.0, labels)
         o.seed_philox(123, c)
         o.shuffle_bisbm()
+        o.anneal("constant", [1.0], 3 * n, BIG)
         assert o.agg_merge_total(5, 10) == 0
         ends.add((o.ka, o.kb))
     assert len(ends) > 1  # the premise: these chains do not agree
-    before = [g.get_memberships(c) for c in (0, 17, 63)]
+    before = [g.get_memberships(c) for c in (0, 17, 31)]
     with pytest.raises(B.BisbmError) as e:
         g.agg_merge(5, None, 10)
     assert e.value.code == B.BISBM_ERR_STATE
     assert (g.KA, g.KB) == (8, 9)
-    for c, lab in zip((0, 17, 63), before):
+    for c, lab in zip((0, 17, 31), before):
         assert (g.get_memberships(c) == lab).all()
-    rates = B.MetropolisHasting().anneal(g, "constant", [1.0], na + nb, BIG)  # the handle is still good
+    rates = mh.anneal(g, "constant", [1.0], n, BIG)  # the handle is still good
     assert (rates > 0).all()
     # the same call on a one-chain handle: the chain's own end point
     solo = gpu_model(rowptr, col, na, nb, 8, 9, 1.0, labels, n_chains=1, rng="philox", seed=123, first_chain_id=17)
     solo.shuffle_bisbm()
+    mh.anneal(solo, "constant", [1.0], 3 * n, BIG)
     solo.agg_merge(5, None, 10)
     o = O.OracleModel(rowptr, col, na, nb, 8, 9, 1.0, labels)
     o.seed_philox(123, 17)
     o.shuffle_bisbm()
+    o.anneal("constant", [1.0], 3 * n, BIG)
     o.agg_merge_total(5, 10)
     assert (solo.KA, solo.KB) == (o.ka, o.kb)
     assert_state_equal(solo, o)
@@ -611,6 +628,64 @@ def test_cli_merge_matches_oracle_replay():
     o.anneal("abrupt_cool", [320.0], 3200, 100000)
     assert r.stdout == " ".join(map(str, o.memberships())) + " \n"
     assert "(Ka, Kb) = (5, 5) " in r.stderr
+
+
+def test_cli_resume_round_trip(tmp_path):
+    """The reference's de-facto checkpoint: print labels, feed them back with --membership_path
+    (mcmc_main.cc:247-278: randomize forced off, KA = max type-a label + 1, KB = max label - max type-a label, -n and
+    -z not needed).  A zero-step continuation must print the same labels and the same description length, i.e.
+    init_bisbm() rebuilt the very state the first run ended in; the edge list comes through the binary CSR cache the
+    second and third time."""
+    import re
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "bipartitesbm-mcmc_amd", "bin", "mcmc")
+    el = str(tmp_path / "n1000.edgelist")
+    shutil.copy(os.path.join(O.GOLDEN, "bisbm-n_1000-ka_4-kb_6.edgelist"), el)
+    first = subprocess.run([cli, "-e", el, "-y", "500", "500", "-n", "125", "125", "125", "125", "84", "84", "83", "83", "83", "83",
+                            "-z", "4", "6", "-t", "20000", "-x", "100000", "-c", "constant", "-a", "1", "-E", "1", "--randomize",
+                            "-d", "7", "--gen_seed", "8"], capture_output=True, text=True)
+    assert first.returncode == 0, first.stderr
+    labels = first.stdout.split()
+    assert len(labels) == 1000
+    mpath = tmp_path / "resume.txt"
+    mpath.write_text("\n".join(labels) + "\n")
+    ent = re.search(r"entropy: (\S+)", first.stderr).group(1)
+
+    def resume(*extra):
+        r = subprocess.run([cli, "-e", el, "-y", "500", "500", "--membership_path", str(mpath), "-t", "0", "-c", "constant",
+                            "-a", "1", "-E", "1", "-d", "99", *extra], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        return r
+    again = resume()
+    assert again.stdout == first.stdout
+    assert "(Ka, Kb) = (4, 6) " in again.stderr and "entropy: %s" % ent in again.stderr
+    assert " ---- read membership from file! ---- " in again.stderr
+    cached = resume("--csr_cache")           # writes <edge list>.bisbm_csr
+    assert os.path.exists(el + ".bisbm_csr") and cached.stdout == first.stdout
+    cached2 = resume("--csr_cache")          # reads it
+    assert cached2.stdout == first.stdout and "entropy: %s" % ent in cached2.stderr
+    # and through the library: the state init_bisbm() builds from the printed labels is the state of the oracle run
+    rowptr, col = B.load_graph(el, 1000, cache=True)
+    assert B.load_graph.last_cache_hit
+    o = O.OracleModel(rowptr, col, 500, 500, 4, 6, 1.0, O.labels_from_sizes([125] * 4 + [84, 84, 83, 83, 83, 83]))
+    o.seed_compat(7, 8)
+    o.shuffle_bisbm()
+    o.anneal("constant", [1.0], 20000, 100000)
+    assert [int(x) for x in labels] == list(o.memberships())
+    g = gpu_model(rowptr, col, 500, 500, 4, 6, 1.0, np.array(labels, dtype=np.uint32), rng="compat", seed=1)
+    g.init_bisbm()
+    assert_state_equal(g, o)
+    # a continuation from the file is a fresh process: new engines, visit list back at 0..N-1 (blockmodel.cc:41)
+    cont = subprocess.run([cli, "-e", el, "-y", "500", "500", "--membership_path", str(mpath), "-t", "5000", "-x", "100000",
+                           "-c", "constant", "-a", "1", "-E", "1", "-d", "31", "--gen_seed", "32"], capture_output=True, text=True)
+    assert cont.returncode == 0, cont.stderr
+    o2 = O.OracleModel(rowptr, col, 500, 500, 4, 6, 1.0, np.array(labels, dtype=np.uint32))
+    o2.seed_compat(31, 32)
+    o2.init_bisbm()
+    o2.anneal("constant", [1.0], 5000, 100000)
+    assert cont.stdout == " ".join(map(str, o2.memberships())) + " \n"
 
 
 # ------------------------------------------------------------------ full size: properties
