@@ -110,12 +110,16 @@ def make_graph(args, pkg, syn):
     na, nb, ka, kb, E = args.na, args.nb, args.ka, args.kb, args.edges
     n = na + nb
     a, b = syn.planted_edges(na, nb, E, ka, kb, seed=1)
+    planted = syn.contiguous_labels(na, nb, ka, kb)  # the generator's own partition
     if args.shuffle_ids:
         rs = np.random.default_rng(7)
         pa, pb = rs.permutation(na).astype(a.dtype), rs.permutation(nb).astype(b.dtype)
         a, b = pa[a], pb[b - na] + na
+        moved = np.empty_like(planted)
+        moved[np.concatenate([pa, pb + na]).astype(np.int64)] = planted
+        planted = moved
     rowptr, col = pkg.edge_to_adj((a, b), n)
-    return rowptr, col
+    return rowptr, col, planted
 
 
 # ----------------------------------------------------------------------------------------------- CPU baseline
@@ -252,7 +256,7 @@ def main():
 
     na, nb, ka, kb, E = args.na, args.nb, args.ka, args.kb, args.edges
     n = na + nb
-    rowptr, col = make_graph(args, pkg, syn)
+    rowptr, col, planted = make_graph(args, pkg, syn)
     reorder = None
     if args.shuffle_ids and not args.no_reorder and hasattr(pkg, "locality_order"):
         # ingest-time reordering pass for ids that carry no structure: the engine runs on the
@@ -260,6 +264,7 @@ def main():
         t0 = time.perf_counter()
         reorder = pkg.locality_order(rowptr, col, na, nb)
         rowptr, col = reorder.apply(rowptr, col)
+        planted = reorder.to_new(planted)
         reorder_s = time.perf_counter() - t0
     labels = syn.contiguous_labels(na, nb, ka, kb)
     shard = pkg.ChainShard(args.chains * world, rank=rank, world_size=world)
@@ -354,7 +359,7 @@ def main():
     # generator), a few sweeps to settle, then timed -- the regime a long marginalize run lives in
     equil = None
     if not args.no_extras:
-        model.set_memberships(labels)
+        model.set_memberships(planted)
         model.init_bisbm()
         for _ in range(3):
             sweep()

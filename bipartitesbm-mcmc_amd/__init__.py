@@ -75,6 +75,8 @@ ABI = {
     "bisbm_io_edges_to_csr": (C.c_int, [_u64p, _u64p, C.c_size_t, C.c_uint64, _u64p, _u32p]),
     "bisbm_io_load_csr": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int, C.POINTER(_u64p), C.POINTER(_u32p), _u64p,
                                     C.POINTER(C.c_int)]),
+    "bisbm_io_locality_order": (C.c_int, [C.c_uint64, C.c_uint64, _u64p, _u32p, _u32p]),
+    "bisbm_io_permute_csr": (C.c_int, [C.c_uint64, _u64p, _u32p, _u32p, _u64p, _u32p]),
     "bisbm_io_format_labels": (C.c_size_t, [_u32p, C.c_size_t, C.c_char_p, C.c_size_t]),
     "bisbm_io_free": (None, [C.c_void_p]),
 }
@@ -208,6 +210,50 @@ def load_graph(path, num_vertices, cache=False):
     L.bisbm_io_free(cl)
     load_graph.last_cache_hit = bool(hit.value)
     return rowptr, col
+
+
+class LocalityOrder:
+    """A renumbering of the nodes (type a within [0, na), type b within [na, n)) made by :func:`locality_order`:
+    ``new_id[v]`` is the id node v has in the renumbered graph."""
+
+    def __init__(self, new_id):
+        self.new_id = np.ascontiguousarray(new_id, dtype=np.uint32)
+        if len(self.new_id) and (self.new_id.max() >= len(self.new_id) or len(np.unique(self.new_id)) != len(self.new_id)):
+            raise ValueError("new_id is not a permutation")
+        self.old_id = np.empty_like(self.new_id)
+        self.old_id[self.new_id] = np.arange(len(self.new_id), dtype=np.uint32)
+
+    def apply(self, rowptr, col):
+        """CSR of the renumbered graph (rows keep their edge order)."""
+        L = lib()
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.uint64)
+        col = np.ascontiguousarray(col, dtype=np.uint32)
+        rp = np.zeros_like(rowptr)
+        cl = np.zeros(max(len(col), 1), dtype=np.uint32)
+        if L.bisbm_io_permute_csr(len(rowptr) - 1, _p(rowptr, _u64p), _p(col, _u32p), _p(self.new_id, _u32p), _p(rp, _u64p),
+                                  _p(cl, _u32p)) != 0:
+            raise ValueError("bad permutation")
+        return rp, cl[: len(col)]
+
+    def to_new(self, per_node):
+        """a per-node vector in the caller's numbering -> the engine's (e.g. initial memberships)"""
+        return np.asarray(per_node)[self.old_id]
+
+    def to_old(self, per_node):
+        """a per-node vector from the engine -> the caller's numbering (e.g. get_memberships())"""
+        return np.asarray(per_node)[self.new_id]
+
+
+def locality_order(rowptr, col, na, nb):
+    """Ingest-time renumbering for graphs whose ids carry no structure (include/bisbm_io.h): returns a LocalityOrder."""
+    L = lib()
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.uint64)
+    col = np.ascontiguousarray(col, dtype=np.uint32)
+    n = int(na) + int(nb)
+    new_id = np.zeros(n, dtype=np.uint32)
+    if L.bisbm_io_locality_order(n, int(na), _p(rowptr, _u64p), _p(col, _u32p), _p(new_id, _u32p)) != 0:
+        raise ValueError("bad graph")
+    return LocalityOrder(new_id)
 
 
 def output_vec(vec, stream=None):

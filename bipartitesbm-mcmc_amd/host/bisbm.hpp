@@ -91,6 +91,23 @@ inline bool load_adj_cached(adj_list_t& adj, const std::string& path, size_t num
     return true;
 }
 
+// Ingest-time renumbering for ids without structure (include/bisbm_io.h): new_id[v] = id of node v in the engine's graph
+inline std::vector<uint32_t> locality_order(const adj_list_t& adj, size_t na) {
+    std::vector<uint32_t> new_id(adj.size());
+    if (bisbm_io_locality_order(adj.size(), na, adj.rowptr.data(), adj.col.data(), new_id.data()) != 0)
+        throw std::runtime_error("locality_order: bad graph");
+    return new_id;
+}
+inline adj_list_t permute_adj(const adj_list_t& adj, const std::vector<uint32_t>& new_id) {
+    adj_list_t out;
+    out.rowptr.assign(adj.rowptr.size(), 0);
+    out.col.assign(adj.col.size() + 1, 0);
+    if (bisbm_io_permute_csr(adj.size(), adj.rowptr.data(), adj.col.data(), new_id.data(), out.rowptr.data(), out.col.data()) != 0)
+        throw std::runtime_error("permute_adj: bad permutation");
+    out.col.resize(adj.col.size());
+    return out;
+}
+
 // ---- output_functions.hh:20-29 ----
 template <typename T>
 void output_vec(const T& vec, std::ostream& stream = std::clog) {

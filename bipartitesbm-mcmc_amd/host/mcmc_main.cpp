@@ -4,7 +4,7 @@
 // partition rules (:241-326), same stdout contract: the label vector through output_vec (trailing blank,
 // newline), "acceptance ratio" and summary() on clog (:483-485).  Boost.program_options is replaced by a
 // small parser with the same surface (long/short names, `--opt=value`, multitoken options).
-// Extra flags: --chains, --device, --rng {mt19937-compat,philox}, --gen_seed, --csr_cache.
+// Extra flags: --chains, --device, --rng {mt19937-compat,philox}, --gen_seed, --csr_cache, --reorder.
 // The agglomerative drivers (:349-451) run through bisbm_agg_merge; block counts are limited to 256 by the label
 // format, so --merge (one block per node to start with) is for graphs of at most 256 nodes.
 // Negative diffs (agg_split) run through the same call (blockmodel.cc:110-117).
@@ -41,7 +41,7 @@ const option_spec kOptions[] = {
     {"seed", 'd', 1},           {"help", 'h', 0},
     // engine extras
     {"chains", 0, 1},           {"device", 0, 1},          {"rng", 0, 1},          {"gen_seed", 0, 1},
-    {"csr_cache", 0, 0},
+    {"csr_cache", 0, 0},        {"reorder", 0, 0},
 };
 
 const option_spec* find_long(const std::string& name) {
@@ -155,6 +155,9 @@ void print_help(const char* argv0) {
                  "  --device arg (=0)                     HIP device ordinal.\n"
                  "  --rng arg (=mt19937-compat)           mt19937-compat (the reference's draw sequence) or philox.\n"
                  "  --gen_seed arg (=seed+1)              Seed of the reference's hidden second engine (blockmodel.hh:18).\n"
+                 "  --reorder                             Renumber the nodes for memory locality before the run (ids without\n"
+                 "                                        structure); labels are read and printed in the caller's numbering.\n"
+                 "                                        The run is a different, equally valid chain than without the flag.\n"
                  "  --csr_cache                           Keep a binary CSR beside the edge list (<path>.bisbm_csr, checked\n"
                  "                                        against the file's size and mtime); the text file stays the input.\n";
 }
@@ -359,6 +362,24 @@ int main(int argc, char const* argv[]) {
         load_edge_list(edge_list, single("edge_list_path", ""));
         adj_list_loaded = edge_to_adj(edge_list, N);
     }
+    // --reorder: the engine works on a renumbered graph; memberships go in and come out in the caller's numbering
+    std::vector<uint32_t> new_id;
+    if (count("reorder")) {
+        new_id = locality_order(adj_list_loaded, NA);
+        adj_list_loaded = permute_adj(adj_list_loaded, new_id);
+        uint_vec_t moved(memberships_init.size());
+        for (size_t v = 0; v < memberships_init.size(); ++v) moved[new_id[v]] = memberships_init[v];
+        memberships_init.swap(moved);
+    }
+    auto emit_labels = [&](const uint_vec_t& engine_labels) {
+        if (new_id.empty()) {
+            output_vec<uint_vec_t>(engine_labels, std::cout);
+            return;
+        }
+        uint_vec_t mine(engine_labels.size());
+        for (size_t v = 0; v < mine.size(); ++v) mine[v] = engine_labels[new_id[v]];
+        output_vec<uint_vec_t>(mine, std::cout);
+    };
     const adj_list_t& adj_list = adj_list_loaded;
 
     // K implied by the initial labels vs. requested (mcmc_main.cc:406-419)
@@ -396,7 +417,7 @@ int main(int argc, char const* argv[]) {
         }
         blockmodel.summary(best);
         if (with_k) std::cout << blockmodel.get_KA() << " " << blockmodel.get_KB() << " ";  // :401-403
-        output_vec<uint_vec_t>(*blockmodel.get_memberships(best), std::cout);
+        emit_labels(*blockmodel.get_memberships(best));
     };
     // one stage per pair of the plan: merge, then a greedy sweep except after the last stage (:380-396, :425-444)
     auto staged_merges = [&](blockmodel_t& blockmodel, metropolis_hasting& algorithm, const std::vector<int>& ka_s,
@@ -489,7 +510,7 @@ int main(int argc, char const* argv[]) {
         }
         std::clog << "acceptance ratio " << algorithm.rates()[best] << "\n";  // :483
         blockmodel.summary(best);                                            // :484
-        output_vec<uint_vec_t>(*blockmodel.get_memberships(best), std::cout);  // :485
+        emit_labels(*blockmodel.get_memberships(best));  // :485
     } catch (const std::exception& e) {
         std::cerr << e.what() << "\n";
         return 3;

@@ -40,6 +40,20 @@ int bisbm_io_edges_to_csr(const uint64_t *a, const uint64_t *b, size_t n_edges, 
 int bisbm_io_load_csr(const char *path, uint64_t n, int use_cache, uint64_t **rowptr, uint32_t **col,
                       uint64_t *n_edges, int *cache_hit);
 
+/* Optional ingest-time renumbering for graphs whose node ids carry no structure.  The production
+ * kernel visits ids in an id-local order and gathers the labels of their neighbours; that pays when nearby ids have
+ * nearby neighbours.  This pass embeds both node types in a few dimensions (power iteration on the degree-normalised
+ * bipartite adjacency, orthonormalised every round: the leading block structure), cuts the embedding with a median
+ * kd-tree shared by both types, and numbers the nodes cell by cell.  new_id[v] is the new id of node v: a bijection
+ * that keeps type-a nodes in [0, na) and type-b nodes in [na, n).  Deterministic.  Purely an optimisation of memory
+ * locality: the engine run on the renumbered graph is a different (equally valid) chain, so this is never applied
+ * behind the caller's back.  Returns 0, or -1 on bad arguments. */
+int bisbm_io_locality_order(uint64_t n, uint64_t na, const uint64_t *rowptr, const uint32_t *col, uint32_t *new_id);
+
+/* CSR of the renumbered graph: row new_id[v] = row v with every neighbour id mapped, order inside rows kept. */
+int bisbm_io_permute_csr(uint64_t n, const uint64_t *rowptr, const uint32_t *col, const uint32_t *new_id,
+                         uint64_t *rowptr_out, uint32_t *col_out);
+
 /* output_vec (output_functions.hh:20-29): every element followed by one blank, then '\n'.
  * Returns the length written (without the NUL); call with out == NULL to size the buffer. */
 size_t bisbm_io_format_labels(const uint32_t *labels, size_t n, char *out, size_t cap);

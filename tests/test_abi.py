@@ -180,3 +180,33 @@ def test_csr_cache_round_trip(built, tmp_path):
         assert (r5[1] == want3[1]).all()
     finally:
         os.chmod(ro, 0o755)
+
+
+def test_locality_order_is_a_type_preserving_bijection_that_localises(built):
+    """bisbm_io_locality_order on a planted graph whose ids were scrambled: a deterministic bijection within each type,
+    the renumbered CSR equals the CSR of the renumbered edge list (rows keep edge order), and the 64-byte label sectors
+    a chunk of 64 consecutive ids gathers from drop back to about what the generator's own numbering needs."""
+    syn = importlib.import_module("bipartitesbm-mcmc_amd.synthetic")
+    na, nb, E, k = 40_000, 30_000, 700_000, 8
+    a, b = syn.planted_edges(na, nb, E, k, k, seed=3)
+    rs = np.random.default_rng(1)
+    pa, pb = rs.permutation(na).astype(np.uint64), rs.permutation(nb).astype(np.uint64)
+    a2, b2 = pa[a.astype(np.int64)], pb[(b - na).astype(np.int64)] + na
+    a2[:5], b2[:5] = a2[5:10], b2[5:10]  # a few duplicate edges
+    n = na + nb + 3                      # three isolated type-b nodes at the end
+    rowptr, col = B.edge_to_adj((a2, b2), n)
+    lo = B.locality_order(rowptr, col, na, nb + 3)
+    assert sorted(lo.new_id[:na]) == list(range(na)) and sorted(lo.new_id[na:]) == list(range(na, n))
+    assert (B.locality_order(rowptr, col, na, nb + 3).new_id == lo.new_id).all()
+    assert (lo.to_old(lo.to_new(np.arange(n))) == np.arange(n)).all()
+    rp2, cl2 = lo.apply(rowptr, col)
+    a3, b3 = lo.new_id[a2.astype(np.int64)].astype(np.uint64), lo.new_id[b2.astype(np.int64)].astype(np.uint64)
+    want = B.edge_to_adj((a3, b3), n)
+    assert (rp2 == want[0]).all() and (cl2 == want[1]).all()
+
+    def sectors_per_chunk(x, y):
+        return len(np.unique((x // 64).astype(np.int64) * (1 << 32) + (y - na) // 64)) / (na / 64)
+    natural, scrambled, ordered = sectors_per_chunk(a, b), sectors_per_chunk(a2, b2), sectors_per_chunk(a3, b3)
+    assert scrambled > 1.5 * natural and ordered < 1.15 * natural, (natural, scrambled, ordered)
+    with pytest.raises(ValueError):
+        B.LocalityOrder(np.array([0, 1, 5], dtype=np.uint32))

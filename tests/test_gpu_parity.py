@@ -688,6 +688,30 @@ def test_cli_resume_round_trip(tmp_path):
     assert cont.stdout == " ".join(map(str, o2.memberships())) + " \n"
 
 
+def test_cli_reorder_runs_the_renumbered_graph_and_prints_the_callers_numbering():
+    """`mcmc --reorder`: the engine runs on the graph renumbered by bisbm_io_locality_order, with the initial labels
+    carried along; stdout is in the caller's numbering.  Replayed with the oracle on the renumbered graph."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "bipartitesbm-mcmc_amd", "bin", "mcmc")
+    el = os.path.join(O.GOLDEN, "bisbm-n_1000-ka_4-kb_6.edgelist")
+    sizes = [125] * 4 + [84, 84, 83, 83, 83, 83]
+    r = subprocess.run([cli, "-e", el, "-y", "500", "500", "-n", *map(str, sizes), "-z", "4", "6", "-t", "10000", "-x", "100000",
+                        "-c", "constant", "-a", "1", "-E", "1", "-d", "3", "--gen_seed", "4", "--reorder"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rowptr, col = B.load_graph(el, 1000)
+    lo = B.locality_order(rowptr, col, 500, 500)
+    rp2, cl2 = lo.apply(rowptr, col)
+    o = O.OracleModel(rp2, cl2, 500, 500, 4, 6, 1.0, lo.to_new(O.labels_from_sizes(sizes)))
+    o.seed_compat(3, 4)
+    o.init_bisbm()
+    o.anneal("constant", [1.0], 10000, 100000)
+    assert r.stdout == " ".join(map(str, lo.to_old(o.memberships()))) + " \n"
+    plain = subprocess.run([cli, "-e", el, "-y", "500", "500", "-n", *map(str, sizes), "-z", "4", "6", "-t", "10000", "-x", "100000",
+                            "-c", "constant", "-a", "1", "-E", "1", "-d", "3", "--gen_seed", "4"], capture_output=True, text=True)
+    assert plain.returncode == 0 and plain.stdout != r.stdout  # (another chain: the visit order is keyed on ids)
+
+
 # ------------------------------------------------------------------ full size: properties
 def test_full_size_properties():
     """BASELINE config 3 graph (N_a=N_b=5e5, E=1e7, Ka=Kb=32) with a handful of chains: one sweep keeps
