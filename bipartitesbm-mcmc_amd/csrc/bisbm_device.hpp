@@ -510,6 +510,34 @@ __device__ __forceinline__ double exp_neg(double t) {
     return ldexp(p, e);
 }
 
+// log_q_approx for u = k / sqrt(n) >= 13 (Philox mode): the fixed point of get_v to SECOND order in x0 = exp(-C0 u),
+// in closed form.  With a = C0 u, v = a (1 - delta) and spence(x) = pi^2/6 - T, T = sum_k (v/k + 1/k^2) x^k, the fixed
+// point v^2 = u^2 spence(exp(-v)) reads (1 - delta)^2 = 1 - T / (pi^2/6), i.e. delta = w/2 + w^2/8 + ..., w = T/(pi^2/6).
+// First order: delta1 = (a + 1) x0 / (2 pi^2/6) (log_q_closed stops here: enough for u > 24).  Feeding v = a (1 - delta1),
+// x = x0 (1 + a delta1) back into T gives T = x0 (a + 1) + x0 delta1 a^2 + (a/2 + 1/4) x0^2 up to terms of relative size
+// (a^2 x0)^2 <= 1e-9 at u = 13 -- of a delta that is itself <= 3e-7: below 1e-15 of the result.  The closing formulas
+// (int_part.cc:94-97) take their logarithms as two-term series (delta, x (1 + u^2/2) <= 5e-6).
+// Against the converged evaluation (orc_log_q_philox): <= 6e-16 relative for u >= 12.5, 3e-14 at u = 11.
+// ~55 straight-line instructions instead of log_q_mid's ~125: once the blocks of a long run have drifted below
+// ~12 000 nodes (u < 24 at mean degree 20) this is the tier the steps live in.
+__device__ __forceinline__ double log_q_closed2(double kd, double sq, double r, double logn, const LogQConsts& c) {
+    const double kInvC6 = 0x1.37423899a1558p-1;  // 1 / (pi^2 / 6)
+    const double u = kd * r;
+    const double a = 0x1.48552f88091a8p+0 * u;  // (pi / sqrt 6) u
+    const double x0 = exp_neg(a);
+    const double d1 = (a + 1.0) * x0 * c.c1;
+    const double T = x0 * (__builtin_fma(d1 * a, a, a + 1.0) + __builtin_fma(0.5, a, 0.25) * x0);
+    const double w = T * kInvC6;
+    const double delta = w * __builtin_fma(0.125, w, 0.5);
+    const double ad = a * delta;
+    const double x = x0 * __builtin_fma(ad, __builtin_fma(0.5, ad, 1.0), 1.0);  // x0 exp(a delta)
+    const double y = x * __builtin_fma(0.5 * u, u, 1.0);
+    // log v - log u = log(pi/sqrt 6) + log(1 - delta);   -log1p(-y)/2 = y (1 + y/2) / 2
+    const double lf = (c.lfc - delta * __builtin_fma(0.5, delta, 1.0)) + 0.5 * y * __builtin_fma(0.5, y, 1.0);
+    const double g = __builtin_fma(c.c2c0, 1.0 - delta, u * x * __builtin_fma(0.5, x, 1.0));  // 2 v / u - u log1p(-x)
+    return (lf - logn) + sq * g;
+}
+
 // log_q_approx for 8 <= u = k / sqrt(n) <= 24 (Philox mode): the reference's formulas (int_part.cc:77-98) with the
 // fixed point v = u sqrt(spence(exp(-v))) of get_v taken to convergence instead of to its |dv| <= 1e-8 stop, and no
 // library calls but one exponential.  With x = exp(-v) <= 3.6e-5 here,
@@ -633,7 +661,8 @@ __device__ inline double log_q_low(double kd, double sq, double r, double logn, 
 // correctly rounded pow can equal an integer only when n is a perfect fourth power, and the distance
 // of n^(1/4) to the nearest integer is otherwise >= 1/(4 j^3) >> ulp, so the two tests agree.
 //
-// FAST (Philox mode only): u > 24 is log_q_closed, 8 <= u <= 24 log_q_mid, 2.5 <= u < 8 log_q_low (all above); smaller
+// FAST (Philox mode only): u > 24 is log_q_closed, 13 <= u <= 24 log_q_closed2, 8 <= u < 13 log_q_mid, 2.5 <= u < 8
+// log_q_low (all above); smaller
 // u take the literal path.
 template <bool FAST>
 __device__ inline double log_q_approx(const Tables& t, unsigned long long n, unsigned long long k, double logn_pre) {
@@ -654,6 +683,7 @@ __device__ inline double log_q_approx(const Tables& t, unsigned long long n, uns
         double r;
         sqrt_rsqrt(nd, sq, r);
         if (__builtin_expect(k2 > 576.0 * nd, 1)) return log_q_closed(kd, sq, r, logn_pre, log_q_consts());
+        if (k2 >= 169.0 * nd) return log_q_closed2(kd, sq, r, logn_pre, log_q_consts());  // u >= 13
         if (k2 >= ldexp(nd, 6)) return log_q_mid(kd, sq, r, logn_pre, log_q_consts());
         if (4.0 * k2 >= 25.0 * nd) return log_q_low(kd, sq, r, logn_pre, log_q_consts());  // u >= 2.5
         u = kd * r;

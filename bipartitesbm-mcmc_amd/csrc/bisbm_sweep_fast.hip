@@ -226,6 +226,7 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
     LogQConsts lqc = log_q_consts();  // log_q closed form
     __asm__ volatile("" : "+v"(lqc.nc0l2e), "+v"(lqc.c1c0), "+v"(lqc.c1), "+v"(lqc.c2c0), "+v"(lqc.lfc));
     BISBM_PIN(c_576, 576.0);                       // 24^2: tier test k^2 > 576 n
+    BISBM_PIN(c_169, 169.0);                       // 13^2: tier test k^2 >= 169 n
     uint64_t sweeps_done = 0;
     // Sum of accepted dS (blockmodel_t::entropy_) and accepted count: lane 0's copy is the value.  They are bumped
     // inside the lane-0 region of an accepted step (a vector add under the execution mask, no LDS round trip).
@@ -645,9 +646,13 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                             double sq, rr;
                             sqrt_rsqrt(nd, sq, rr);
                             lq = log_q_closed(kd, sq, rr, logn, lqc);
+                        } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= c_169 * nd)) == 0) {
+                            double sq, rr;  // u >= 13 everywhere: second-order closed form (also right for u > 24)
+                            sqrt_rsqrt(nd, sq, rr);
+                            lq = log_q_closed2(kd, sq, rr, logn, lqc);
                         } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= ldexp(nd, 6))) == 0) {
-                            // blocks of a few thousand nodes (8 <= u <= 24 for some of the four arguments): the
-                            // converged tier, and the closed form where it applies -- both straight-line code
+                            // blocks of a thousand to a few thousand nodes (8 <= u < 13 for some of the four arguments):
+                            // the converged tier, and the closed form where it applies -- both straight-line code
                             double sq, rr;
                             sqrt_rsqrt(nd, sq, rr);
                             const double lq_mid = log_q_mid(kd, sq, rr, logn, lqc);
@@ -803,6 +808,12 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                             double sq, rr;
                             sqrt_rsqrt(nd, sq, rr);
                             lq = log_q_closed(kd, sq, rr, logn, lqc);
+                        } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= c_169 * nd)) == 0) {
+                            // u >= 13 in every lane (blocks of a few thousand nodes): the second-order closed form, which
+                            // also serves the lanes with u > 24
+                            double sq, rr;
+                            sqrt_rsqrt(nd, sq, rr);
+                            lq = log_q_closed2(kd, sq, rr, logn, lqc);
                         } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= ldexp(nd, 6))) == 0) {
                             double sq, rr;
                             sqrt_rsqrt(nd, sq, rr);
