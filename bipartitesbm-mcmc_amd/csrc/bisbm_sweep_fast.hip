@@ -729,15 +729,18 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
                                                                          // select of uniform values goes through the vector unit and back)
                     const int sel = (int)(qs << 2);
                     FSTAMP_STEP(0);
-                    const uint32_t pack = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)pack_l);
                     const uint32_t prop = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)prop_l);
                     const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)v_l);
                     const double u_acc = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(ud_acc)),
                                                           __builtin_amdgcn_ds_bpermute(sel, __double2loint(ud_acc)));
                     const uint32_t packA = readlane(pack_l, q), packB = readlane(pack_l, qB);
                     const uint32_t r_locA = (packA >> 8) & 63u, r_locB = (packB >> 8) & 63u;
-                    const uint32_t degA = packA & 255u, degB = packB & 255u, t_locB = packB >> 16;
-                    const uint32_t deg = pack & 255u, r_loc = (pack >> 8) & 63u, t_loc = pack >> 16;
+                    const uint32_t degA = packA & 255u, degB = packB & 255u, t_locA = packA >> 16, t_locB = packB >> 16;
+                    // the lane's own step: lower half step q, upper half step qB (from the two scalars: no LDS round trip
+                    // in front of the first reads)
+                    const uint32_t deg = (uint32_t)((int)degA + __mul24((int)half, (int)degB - (int)degA));
+                    const uint32_t r_loc = (uint32_t)((int)r_locA + __mul24((int)half, (int)r_locB - (int)r_locA));
+                    const uint32_t t_loc = (uint32_t)((int)t_locA + __mul24((int)half, (int)t_locB - (int)t_locA));
                     const int k = (int)hist8_cur[qs * kHistStride + lb];
                     const uint32_t a_rt = mq_at(r_loc, lb);
                     const int32_t m_rt_raw = mq[a_rt];
