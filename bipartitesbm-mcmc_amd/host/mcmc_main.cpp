@@ -435,6 +435,12 @@ int main(int argc, char const* argv[]) {
         return true;
     };
     if (merge) {
+        if (NA + NB > 256) {  // the start is one block per node (:350-353); block labels are bytes on the device
+            std::cerr << "[error] --merge starts from one block per node (" << NA + NB << " blocks); this engine holds at most 256 "
+                         "blocks. Start from an initial partition of at most 256 blocks (-n / --mb / --membership_path with a "
+                         "larger -z than wanted is merged down the same way, mcmc_main.cc:419-450).\n";
+            return 3;
+        }
         try {
             std::iota(memberships_init.begin(), memberships_init.end(), 0);  // every node its own block (:350)
             blockmodel_t blockmodel(memberships_init, types_init, NA + NB, NA, NB, epsilon, &adj_list, opt);

@@ -155,6 +155,66 @@ def test_hot_step_many_chains_philox():
         assert cum[c] == pytest.approx(o.get_entropy(), rel=1e-9)
 
 
+def test_two_steps_per_pass_equals_the_serial_chain(monkeypatch):
+    """K = 32 + 32 at constant T: the production kernel evaluates steps q and q+1 in the two halves of the wave and
+    commits both when step q provably left step q+1's inputs alone.  Many blocks make that the
+    common case (with K = 2 + 2 nearly every pair clashes), so this is the test of the commit-both path: chains equal
+    their oracle runs sweep by sweep -- from a randomised start (most steps move) and from the planted partition (most
+    proposals are r == s) -- and equal the same kernel forced to one step per pass."""
+    na = nb = 24_000
+    ka = kb = 32
+    rowptr, col = _random_graph(5, na, nb, 480_000, ka, kb)
+    n = na + nb
+    planted = O.contiguous_labels(na, nb, ka, kb)
+    mh = B.MetropolisHasting()
+    chains = 6
+    for start in ("randomised", "planted"):
+        g = gpu_model(rowptr, col, na, nb, ka, kb, 1.0, planted, n_chains=chains, rng="philox", seed=77, first_chain_id=2)
+        monkeypatch.setenv("BISBM_SINGLE_STEPS", "1")
+        h = gpu_model(rowptr, col, na, nb, ka, kb, 1.0, planted, n_chains=chains, rng="philox", seed=77, first_chain_id=2)
+        if start == "randomised":
+            h.shuffle_bisbm()
+        else:
+            h.init_bisbm()
+        single = [mh.anneal(h, "constant", [1.0], n, BIG).copy() for _ in range(3)]
+        monkeypatch.delenv("BISBM_SINGLE_STEPS")
+        oracles = []
+        for c in (0, chains - 1):
+            o = O.OracleModel(rowptr, col, na, nb, ka, kb, 1.0, planted)
+            o.seed_philox(77, 2 + c)
+            oracles.append((c, o))
+        if start == "randomised":
+            g.shuffle_bisbm()
+            for _, o in oracles:
+                o.shuffle_bisbm()
+        else:
+            g.init_bisbm()
+            for _, o in oracles:
+                o.init_bisbm()
+        for sweep in range(3):
+            rates = mh.anneal(g, "constant", [1.0], n, BIG)
+            assert (rates == single[sweep]).all()
+            for c, o in oracles:
+                assert o.anneal("constant", [1.0], n, BIG) == rates[c], (start, sweep, c)
+                assert_state_equal(g, o, c)
+        for c in range(chains):
+            assert (g.get_memberships(c) == h.get_memberships(c)).all()
+        assert np.allclose(g.get_entropy(), h.get_entropy(), rtol=0, atol=0)  # same sum, same order of additions
+        for c, o in oracles:
+            assert g.get_entropy()[c] == pytest.approx(o.get_entropy(), rel=1e-9)
+    # a temperature other than 1 and a chunk that ends on an odd step (n_own not a multiple of 64)
+    rowptr, col = _random_graph(6, 1003, 777, 30_000, 7, 5)
+    lab = O.contiguous_labels(1003, 777, 7, 5)
+    g = gpu_model(rowptr, col, 1003, 777, 7, 5, 0.5, lab, n_chains=3, rng="philox", seed=9)
+    g.shuffle_bisbm()
+    o = O.OracleModel(rowptr, col, 1003, 777, 7, 5, 0.5, lab)
+    o.seed_philox(9, 1)
+    o.shuffle_bisbm()
+    for T in (2.5, 0.7):
+        assert mh.anneal(g, "constant", [T], 4 * 1780, BIG)[1] == o.anneal("constant", [T], 4 * 1780, BIG)
+        assert_state_equal(g, o, 1)
+
+
 @pytest.mark.parametrize("roles", ["claims", "1", "2"])
 def test_either_wave_can_step(roles, monkeypatch):
     """The production kernel settles at start which of a workgroup's two waves steps (per-SIMD claims); whichever it is
