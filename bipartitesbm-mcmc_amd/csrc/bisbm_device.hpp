@@ -517,7 +517,7 @@ __device__ __forceinline__ double exp_neg(double t) {
 // x = x0 (1 + a delta1) back into T gives T = x0 (a + 1) + x0 delta1 a^2 + (a/2 + 1/4) x0^2 up to terms of relative size
 // (a^2 x0)^2 <= 1e-9 at u = 13 -- of a delta that is itself <= 3e-7: below 1e-15 of the result.  The closing formulas
 // (int_part.cc:94-97) take their logarithms as two-term series (delta, x (1 + u^2/2) <= 5e-6).
-// Against the converged evaluation (orc_log_q_philox): <= 6e-16 relative for u >= 12.5, 3e-14 at u = 11.
+// Against the converged evaluation (the CPU checker's Philox-mode log_q): <= 6e-16 relative for u >= 12.5, 3e-14 at u = 11.
 // ~55 straight-line instructions instead of log_q_mid's ~125: once the blocks of a long run have drifted below
 // ~12 000 nodes (u < 24 at mean degree 20) this is the tier the steps live in.
 __device__ __forceinline__ double log_q_closed2(double kd, double sq, double r, double logn, const LogQConsts& c) {
