@@ -257,7 +257,10 @@ __global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
             int& mr_own = TB ? mrB : mrA;
             int& nr_own = TB ? nrB : nrA;
             const int mr_oth = TB ? mrA : mrB;             // frozen during the phase
-            const double inv_oth = 1.0 / (mr_oth + epsK);  // 1 / (m_r[t] + eps K), lane t <-> opposite block t
+            // 1 / (m_r[t] + eps K), lane t <-> opposite block t.  With epsilon = 0 the denominator is zero for idle lanes and
+            // for blocks without edges; their k is zero, and 0 * finite * 0 keeps their leaves at zero (0 * inf would not)
+            const double den_oth = mr_oth + epsK;
+            const double inv_oth = den_oth > 0. ? 1.0 / den_oth : 0.;
             // m[own block i][opposite block j] in the a x b quadrant
             auto mq_at = [&](uint32_t i_own, uint32_t j_oth) -> uint32_t {
                 return TB ? j_oth * S + i_own : i_own * S + j_oth;

@@ -39,6 +39,9 @@ CASES = [
     ("mid_tier_low", 2400, 2400, 28800, 2, 2, 1.0, 0, 0),
     # ... and a dense graph (mean degree 40, blocks of 1000 nodes): k / sqrt(n) around 5, the low converged tier
     ("dense_low_tier", 2000, 2000, 80000, 2, 2, 1.0, 0, 0),
+    # epsilon = 0 (legal in the reference: -E 0): no uniform component in the proposal, denominators m_r[t] alone
+    ("eps0", 300, 200, 3000, 5, 7, 0.0, 0, 4),
+    ("eps0_direct", 20000, 20000, 100000, 2, 2, 0.0, 0, 0),
     # no edges at all: every node has degree 0 (uniform proposals over all K blocks, blockmodel.cc:616-617)
     ("edgeless", 10, 8, 0, 2, 2, 1.0, 0, 0),
 ]
