@@ -113,7 +113,7 @@ constexpr uint32_t kRowCap = 255;     // longest row the feeder walks (a k_v cou
 
 // EL: eta in LDS.  CT: constant schedule.  K32: both block counts <= 32 (five-level scans and sums).
 template <bool EL, bool CT, bool K32>
-__global__ __launch_bounds__(2 * kWave) void sweep_fast_kernel(SweepParams p) {
+__global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p) {
     extern __shared__ __align__(16) uint32_t lds32[];
     const uint32_t chain = blockIdx.x;
     if (chain >= p.n_chains) return;
