@@ -250,9 +250,7 @@ def main():
     pkg = importlib.import_module("bipartitesbm-mcmc_amd")
     syn = importlib.import_module("bipartitesbm-mcmc_amd.synthetic")
     if not os.path.exists(pkg.LIB_PATH):
-        if world > 1:
-            raise SystemExit("libbisbm_hip.so is missing: build it once before starting the ranks (__graft_entry__.build())")
-        pkg.build()
+        pkg.build()  # (under a file lock: with several ranks one compiles, the others wait)
 
     na, nb, ka, kb, E = args.na, args.nb, args.ka, args.kb, args.edges
     n = na + nb

@@ -41,8 +41,22 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
+    """Compile the library (and the CLI) in-tree.  Safe to call from several processes at once (the ranks of a
+    multi-GPU job on a fresh checkout): one holds the lock and compiles, the others wait and find the result."""
+    import fcntl
     if not force and not needs_build():
         return LIB
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
     extra = os.environ.get("BISBM_EXTRA_HIPCC_FLAGS", "").split()  # diagnostic builds (e.g. -DBISBM_ABLATE=1)
     cmd = [hipcc()] + FLAGS + extra + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
