@@ -216,8 +216,9 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     const bool never_direct = (p.rowptr[n] >> 1) + p.maxdeg <= (uint32_t)kQNmax;
     // the early-stop bookkeeping can only ever fire below T = 1, and only if steps_await can be reached within the call
     // (the counter starts at 0 and gains at most 1 per step) -- a scalar word, not a lane mask: one s_cmp to test
-    // two steps per pass (step_pair): K <= 32, constant T > 0; p.pair_steps == 0 switches it off (A/B runs, tests)
-    const bool pair_mode = (uint32_t)__builtin_amdgcn_readfirstlane((K32 && CT && T_const > 0. && p.pair_steps != 0) ? 1 : 0) != 0u;
+    // two steps per pass (step_pair): K <= 32 (a constant schedule at T = 0 takes the general step anyway);
+    // p.pair_steps == 0 switches it off (A/B runs, tests)
+    const bool pair_mode = (uint32_t)__builtin_amdgcn_readfirstlane((K32 && (!CT || T_const > 0.) && p.pair_steps != 0) ? 1 : 0) != 0u;
     const uint32_t track_min =
         (uint32_t)__builtin_amdgcn_readfirstlane(((!CT || T_const < 1.) && p.steps_await <= p.duration) ? 1 : 0);
     // constants of the hot step (log_q closed form, accept filter)
@@ -726,7 +727,10 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 const uint32_t pack_l = (deg_l & 255u) | ((rloc_l & 63u) << 8) | (tloc_l << 16);
                 // q: first step of the pass; pairable: 1 = lanes 32..63 evaluate step q + 1, 0 = nothing to pair with
                 // (last step of the chunk, or a step that needs the general path next): both halves evaluate step q
-                auto step_pair = [&](uint32_t q, uint32_t pairable) -> uint32_t {
+                // (cooling schedules: the temperature is the lane's own step's; steps at T = 0 are decided by the sign of dS)
+                const unsigned long long zeroT_mask = CT ? 0ull : __builtin_amdgcn_ballot_w64(T_l == 0.);
+                auto step_pair = [&](auto tm, uint32_t q, uint32_t pairable) -> uint32_t {
+                    constexpr bool TM = decltype(tm)::value;
                     const uint32_t qB = q + pairable;
                     const uint32_t qs = q + (half & (0u - pairable));  // (flags are 0 / 1 words and selections arithmetic: a bool
                                                                          // select of uniform values goes through the vector unit and back)
@@ -765,9 +769,12 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     __asm__("s_ff1_i32_b32 %0, %1" : "=s"(fhB) : "s"((uint32_t)(hit >> 32)));
                     const uint32_t s_locA = min(fhA, last_own), s_locB = min(fhB, last_own);
                     const uint32_t selfA = 1u - sflag(s_locA ^ r_locA), selfB = 1u - sflag(s_locB ^ r_locB);
+                    // T = 0 (the greedy tail of a cooling schedule): r == s is not accepted (dS = 0 is not < 0, :49-50)
+                    const uint32_t warmA = CT ? 1u : ((uint32_t)(zeroT_mask >> q) & 1u) ^ 1u;
+                    const uint32_t warmB = CT ? 1u : ((uint32_t)(zeroT_mask >> qB) & 1u) ^ 1u;
                     FSTAMP_STEP(2);
                     if ((selfA & selfB) != 0u) {  // both r == s: nothing changes (:109-112)
-                        acc_chunk += liveA + liveB;
+                        acc_chunk += (liveA & warmA) + (liveB & warmB);
                         return 1u + pairable;
                     }
                     // Would step q, if it moves its node, touch what step q + 1 read?  (block sets as bit masks)
@@ -778,8 +785,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t clash = sflag(setA & setB) | (((between >> s_locB) & 1u) & sflag(kAtB));
                     // what the verdicts will be combined with, in one word (the scalar file is full): bit 0 step q can
                     // move, bit 1 step q is an accepted r == s, bits 2, 3 the same for step q + 1, bit 4 the clash
-                    const uint32_t flags = (liveA & (selfA ^ 1u)) | ((liveA & selfA) << 1) | ((liveB & (selfB ^ 1u)) << 2) |
-                                           ((liveB & selfB) << 3) | (clash << 4);
+                    const uint32_t flags = (liveA & (selfA ^ 1u)) | ((liveA & selfA & warmA) << 1) | ((liveB & (selfB ^ 1u)) << 2) |
+                                           ((liveB & selfB & warmB) << 3) | (clash << 4);
 
                     const uint32_t s_loc = (uint32_t)((int)s_locA + __mul24((int)half, (int)s_locB - (int)s_locA));
                     const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
@@ -837,13 +844,24 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double dS = butterfly_rows32(d);
                     FSTAMP_STEP(6);
                     // accept (:47-61) in the lanes that hold the sums; bit 31 is step q's verdict, bit 63 step q + 1's
-                    const double z = -dS * invT_const;
+                    double invT = invT_const;
+                    if (!CT) invT = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(invT_l)),
+                                                     __builtin_amdgcn_ds_bpermute(sel, __double2loint(invT_l)));
+                    const double z = -dS * invT;
                     const double est = accu1 * exp2_filter(z * c_l2e);
                     const double lhs = u_acc * accu0;
                     unsigned long long b_acc = __builtin_amdgcn_ballot_w64(lhs < est);
-                    const unsigned long long b_far = __builtin_amdgcn_ballot_w64(fabs(lhs - est) > c_tol * est);
-                    if (__builtin_expect((((uint32_t)b_far & (uint32_t)(b_far >> 32)) >> 31) == 0u, 0))  // a verdict too close to call
-                        b_acc = __builtin_amdgcn_ballot_w64(lhs < accu1 * exp(z));
+                    unsigned long long b_far = __builtin_amdgcn_ballot_w64(fabs(lhs - est) > c_tol * est);
+                    if (!CT) {  // steps at T = 0: dS < 0 decides (:49-50); nothing to be close to
+                        const unsigned long long cold = ((unsigned long long)(0u - (warmB ^ 1u)) << 32) | (0u - (warmA ^ 1u));
+                        const unsigned long long b_neg = __builtin_amdgcn_ballot_w64(dS < 0.);
+                        b_acc = (b_acc & ~cold) | (b_neg & cold);
+                        b_far |= cold;
+                    }
+                    if (__builtin_expect((((uint32_t)b_far & (uint32_t)(b_far >> 32)) >> 31) == 0u, 0)) {  // a verdict too close to call
+                        const unsigned long long exact = __builtin_amdgcn_ballot_w64(lhs < accu1 * exp(z));
+                        b_acc = (b_acc & b_far) | (exact & ~b_far);
+                    }
                     FSTAMP_STEP(7);
                     const uint32_t yesA = (uint32_t)(b_acc >> 31) & 1u, yesB = (uint32_t)(b_acc >> 63) & 1u;
                     const uint32_t chA = flags & yesA;                                  // step q moves its node
@@ -872,31 +890,40 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         nr_own += __mul24((int)chA, dlA) + __mul24((int)chB, dlB);
                         // :500, in step order; a step that does not move adds +0.0 (x + 0.0 is x: the running sum is never -0.0)
                         cum_l0 += __hiloint2double(dS_A_hi & (int)mA, dS_A_lo & (int)mA);
+                        if constexpr (TM)
+                            if (chA) new_minimum(q);  // (:86-90, after step q's move and before step q + 1's)
                         cum_l0 += __hiloint2double(dS_B_hi & (int)mB, dS_B_lo & (int)mB);
+                        if constexpr (TM)
+                            if (chB) new_minimum(qB);
                         wfence();
                     }
                     FSTAMP_STEP(8);
                     return 1u + stands;
                 };
 
-                constexpr bool kPairs = K32 && CT;
-                if (track_min != 0u) {
-                    for (uint32_t q = 0; q < cnt; ++q) step(std::true_type{}, q);
-                } else if (kPairs && pair_mode) {
-                    // steps that need the general path (bit 31 of prop_l) go one at a time
+                // steps that need the general path (bit 31 of prop_l) go one at a time
+                auto pair_loop = [&](auto tm) {
                     const unsigned long long gen_mask = __builtin_amdgcn_ballot_w64((int32_t)prop_l < 0);
                     uint32_t q = 0;
                     acc_chunk = 0;
                     while (q < cnt) {
                         const uint32_t two = (uint32_t)(gen_mask >> q) & 3u;
                         if (__builtin_expect((two & 1u) != 0u, 0)) {
-                            step_general(q, T_const);
+                            step_general(q, CT ? T_const : readlane(T_l, q));
                             q += 1u;
                         } else {
-                            q += step_pair(q, ((two >> 1) ^ 1u) & sflag(cnt - 1u - q));
+                            q += step_pair(tm, q, ((two >> 1) ^ 1u) & sflag(cnt - 1u - q));
                         }
                     }
                     acc_l0 += (unsigned long long)acc_chunk;
+                };
+                if (K32 && pair_mode) {
+                    if (track_min != 0u)
+                        pair_loop(std::true_type{});
+                    else
+                        pair_loop(std::false_type{});
+                } else if (track_min != 0u) {
+                    for (uint32_t q = 0; q < cnt; ++q) step(std::true_type{}, q);
                 } else {
                     for (uint32_t q = 0; q < cnt; ++q) step(std::false_type{}, q);
                 }
