@@ -207,6 +207,7 @@ struct bisbm_engine {
     uint32_t* d_stage_u32 = nullptr;  // n uint32 staging
     uint32_t* d_counts = nullptr;     // internal marginal buffer n*kmax
     uint32_t counts_kmax = 0;         // columns d_counts was sized for
+    uint32_t counts_cols = 0;         // columns of the histogram it currently holds (max(KA, KB) at the last reset)
     uint32_t cap_ka = 0, cap_kb = 0;  // block counts d_m / d_m_r / d_n_r / d_eta are allocated for
     std::shared_ptr<HostTables> tab;
     uint32_t q_stride = 0;
@@ -779,6 +780,7 @@ int bisbm_marginals_reset(bisbm_handle h) {
         HIPCHK(h, dalloc(&h->d_counts, cnt));
         h->counts_kmax = kmax;
     }
+    h->counts_cols = kmax;
     HIPCHK(h, hipMemsetAsync(h->d_counts, 0, sizeof(uint32_t) * cnt, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return BISBM_OK;
@@ -788,7 +790,8 @@ int bisbm_marginals_accumulate(bisbm_handle h, uint32_t* device_counts) {
     if (!h) return BISBM_ERR_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     if (!device_counts) {
-        if (!h->d_counts) {
+        // (a histogram made before a merge / split changed max(KA, KB) has another row length: start afresh)
+        if (!h->d_counts || h->counts_cols != std::max(h->ka, h->kb)) {
             int rc = bisbm_marginals_reset(h);
             if (rc) return rc;
         }
@@ -812,6 +815,9 @@ int bisbm_marginals_get(bisbm_handle h, uint32_t* counts_out) {
     if (!h) return BISBM_ERR_INVALID_ARG;
     if (!counts_out) return fail(h, BISBM_ERR_INVALID_ARG, "counts_out is NULL");
     if (!h->d_counts) return fail(h, BISBM_ERR_STATE, "no internal marginal buffer yet");
+    if (h->counts_cols != std::max(h->ka, h->kb))
+        return fail(h, BISBM_ERR_STATE, "the block counts changed since the histogram was made (%u columns then, %u now)", h->counts_cols,
+                    std::max(h->ka, h->kb));
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(counts_out, h->d_counts, sizeof(uint32_t) * (size_t)h->n * std::max(h->ka, h->kb), hipMemcpyDeviceToHost));
