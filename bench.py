@@ -237,15 +237,35 @@ def main():
     # one process per GPU; BISBM_BENCH_BACKEND=gloo lets the multi-rank path be rehearsed on a one-GPU box
     # (several ranks then share device 0 and the collectives run on CPU tensors)
     backend = os.environ.get("BISBM_BENCH_BACKEND", "nccl")
+    backend_note = None
     device_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
-    coll_device = torch.device("cuda", device_index) if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+            try:
+                import datetime
+                dist.init_process_group("nccl", device_id=torch.device("cuda", device_index),
+                                        timeout=datetime.timedelta(seconds=180))
+                probe = torch.ones(1, device=torch.device("cuda", device_index))
+                dist.all_reduce(probe)  # the first collective is where a broken RCCL setup shows
+                torch.cuda.synchronize()
+            except Exception as exc:  # the sweep path has no collective: the measurement does not depend on RCCL
+                backend_note = "nccl unusable (%s: %s); timing coordination and pooling over gloo" % (type(exc).__name__, str(exc)[:200])
+                print("bench.py rank %d: %s" % (rank, backend_note), file=sys.stderr, flush=True)
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+                # (a store of our own: under torchrun the workers are clients of the agent's store on MASTER_PORT)
+                import datetime as _dt
+                store = dist.TCPStore("127.0.0.1", int(os.environ.get("MASTER_PORT", "29500")) + 1, world, is_master=(rank == 0),
+                                      timeout=_dt.timedelta(seconds=120))
+                backend = "gloo"
+                dist.init_process_group("gloo", store=store, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend)
+    coll_device = torch.device("cuda", device_index) if backend == "nccl" else torch.device("cpu")
 
     pkg = importlib.import_module("bipartitesbm-mcmc_amd")
     syn = importlib.import_module("bipartitesbm-mcmc_amd.synthetic")
@@ -435,6 +455,7 @@ def main():
                 "spinup_sweeps_before_warmup": len(spin_ms),
                 "accepted_fraction_last_timed_sweep": accepted_frac,
                 "parallelism": "chains sharded, no collective in the sweep path",
+                "collective_backend": (backend if world > 1 else None), "collective_backend_note": backend_note,
             },
             "roofline": roofline,
             "equilibrated_start": equil,
