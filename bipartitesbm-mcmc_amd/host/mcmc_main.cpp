@@ -9,6 +9,7 @@
 // format, so --merge (one block per node to start with) is for graphs of at most 256 nodes.
 // Negative diffs (agg_split) run through the same call (blockmodel.cc:110-117).
 #include <chrono>
+#include <limits>
 #include <cmath>
 #include <numeric>
 #include <cstdlib>
@@ -443,6 +444,50 @@ int main(int argc, char const* argv[]) {
         }
         try {
             std::iota(memberships_init.begin(), memberships_init.end(), 0);  // every node its own block (:350)
+            if (nature && opt.n_chains > 1) {
+                // agg_merge(engine, diff, nm) lets every run end with its own (Ka,Kb) (blockmodel.cc:208-271) and a handle
+                // has one block count for all its chains: --nature --chains N runs the N chains one after the other, each
+                // in a handle of its own with its global chain id (same streams as in one handle), and prints the best
+                double best_dl = std::numeric_limits<double>::infinity();
+                uint_vec_t best_labels;
+                size_t best_ka = 0, best_kb = 0, best_chain = 0;
+                for (uint32_t c = 0; c < opt.n_chains; ++c) {
+                    engine_options one = opt;
+                    one.n_chains = 1;
+                    one.first_chain_id = opt.first_chain_id + c;
+                    blockmodel_t blockmodel(memberships_init, types_init, NA + NB, NA, NB, epsilon, &adj_list, one);
+                    blockmodel.init_bisbm();
+                    metropolis_hasting algorithm;
+                    size_t tKA = NA, tKB = NB, tGroups = NA + NB;
+                    const size_t ceiling = (size_t)std::ceil(std::sqrt(2. * blockmodel.get_num_edges()) / 2);
+                    while (tKA >= ceiling && tKB >= ceiling) {  // :357-377
+                        blockmodel.agg_merge((int)std::ceil(tGroups * (sigma - 1) / sigma), 10);
+                        tKA = blockmodel.get_KA();
+                        tKB = blockmodel.get_KB();
+                        tGroups = tKA + tKB;
+                        if (cooling_schedule != "abrupt_cool") {
+                            std::cerr << "Only abrupt cooling annealing is supported.";
+                            return 1;
+                        }
+                        algorithm.anneal(blockmodel, &abrupt_cool_schedule, agg_merge_kwargs, (NA + NB) * 1, steps_await);
+                    }
+                    algorithm.anneal(blockmodel, &abrupt_cool_schedule, kwargs, sampling_steps, steps_await);  // :398
+                    const double dl = blockmodel.entropy_all()[0];
+                    if (dl < best_dl) {
+                        best_dl = dl;
+                        best_labels = *blockmodel.get_memberships(0);
+                        best_ka = blockmodel.get_KA();
+                        best_kb = blockmodel.get_KB();
+                        best_chain = c;
+                    }
+                }
+                std::clog << "chains " << opt.n_chains << ", printing chain " << best_chain << "\n";
+                std::clog << "(Ka, Kb) = (" << best_ka << ", " << best_kb << ") \n";  // summary(), blockmodel.cc:748-751
+                std::clog << "entropy: " << best_dl << "\n";
+                std::cout << best_ka << " " << best_kb << " ";  // :401-403
+                emit_labels(best_labels);
+                return 0;
+            }
             blockmodel_t blockmodel(memberships_init, types_init, NA + NB, NA, NB, epsilon, &adj_list, opt);
             blockmodel.init_bisbm();
             metropolis_hasting algorithm;

@@ -535,6 +535,39 @@ def test_agg_merge_total_refuses_diverging_chains():
     assert_state_equal(solo, o)
 
 
+def test_cli_nature_with_several_chains():
+    """`mcmc --merge --nature --chains 3` (mcmc_main.cc:354-377,398-404): every chain may end with its own (Ka,Kb), so
+    the shell runs them in handles of their own and prints "KA KB labels" of the chain with the lowest description
+    length -- replayed with three oracle runs."""
+    import math
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "bipartitesbm-mcmc_amd", "bin", "mcmc")
+    r = subprocess.run([cli, "-e", os.path.join(O.GOLDEN, "southernWomen.edgelist"), "-y", "18", "14", "-n", "18", "14", "-z", "1", "1",
+                        "--merge", "--nature", "--chains", "3", "-t", "640", "-x", "100000", "-c", "abrupt_cool", "-a", "320",
+                        "-E", "0.001", "-d", "42", "--gen_seed", "43"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rowptr, col, na, nb = O.load_graph("southernWomen")
+    n = na + nb
+    best = None
+    for c in range(3):
+        o = O.OracleModel(rowptr, col, na, nb, na, nb, 0.001, np.arange(n, dtype=np.uint32))
+        o.seed_compat(42 + c, 43 + c)
+        o.init_bisbm()
+        ceiling = math.ceil(math.sqrt(2.0 * o.num_edges) / 2)
+        tka, tkb = na, nb
+        while tka >= ceiling and tkb >= ceiling:
+            assert o.agg_merge_total(math.ceil((tka + tkb) * (1.01 - 1) / 1.01), 10) == 0
+            tka, tkb = o.ka, o.kb
+            o.anneal("abrupt_cool", [0.0], n, 100000)
+        o.anneal("abrupt_cool", [320.0], 640, 100000)
+        dl = o.entropy()
+        if best is None or dl < best[0]:
+            best = (dl, o.ka, o.kb, o.memberships().copy(), c)
+    assert r.stdout == "%d %d " % (best[1], best[2]) + " ".join(map(str, best[3])) + " \n"
+    assert "printing chain %d" % best[4] in r.stderr and "(Ka, Kb) = (%d, %d) " % (best[1], best[2]) in r.stderr
+
+
 def test_cli_split_matches_oracle_replay():
     """`mcmc` with -z larger than the initial partition (mcmc_main.cc:419-451, else branch: agg_merge(diff_a, diff_b,
     100) with negative diffs = agg_split, then the final anneal) against the same driver replayed with the oracle."""
