@@ -1276,7 +1276,7 @@ int run_split(bisbm_engine* h, int type, int nm) {
         SCHK(hipStreamSynchronize(h->stream));
         SCHK(hipMemcpy(out_k.data(), d_out_k, sizeof(int32_t) * C * nt * k_type * k_oth, hipMemcpyDeviceToHost));
         SCHK(hipMemcpy(out_deg.data(), d_out_deg, sizeof(int32_t) * C * nt * k_type, hipMemcpyDeviceToHost));
-        for (size_t c = 0; c < C; ++c)
+        auto eval_chain = [&](size_t c) {
             for (size_t b = 0; b < k_type; ++b) {
                 if (n_r[c * K + b_lo + b] <= 1) continue;
                 for (size_t j = 0; j < nt; ++j) {
@@ -1306,6 +1306,18 @@ int run_split(bisbm_engine* h, int type, int nm) {
                     }
                 }
             }
+        };
+        const unsigned n_thr = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, std::thread::hardware_concurrency()), C / 4));
+        if (n_thr <= 1) {
+            for (size_t c = 0; c < C; ++c) eval_chain(c);
+        } else {  // chains are independent
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < n_thr; ++t)
+                th.emplace_back([&, t] {
+                    for (size_t c = t; c < C; c += n_thr) eval_chain(c);
+                });
+            for (auto& x : th) x.join();
+        }
     }
     std::vector<uint32_t> chosen(2 * C);
     for (size_t c = 0; c < C; ++c) {
@@ -1420,8 +1432,10 @@ int run_merges(bisbm_engine* h, int which, int diff_a, int diff_b, int nm) {
     };
 
     std::vector<uint8_t> fmap(C * 256, 0);
-    size_t nka = 0, nkb = 0;
-    for (size_t c = 0; c < C; ++c) {
+    // the chains are independent: K-scale selection per chain, spread over the host's threads
+    std::vector<int> rcs(C, 0);
+    std::vector<std::pair<size_t, size_t>> ends(C);
+    auto one_chain = [&](size_t c) {
         MergeChain mc;
         mc.K = K0, mc.ka = ka0, mc.kb = kb0, mc.na = (size_t)h->na;
         mc.M.assign(K0 * K0, 0);
@@ -1448,28 +1462,45 @@ int run_merges(bisbm_engine* h, int which, int diff_a, int diff_b, int nm) {
             load_mt(mc.gen, &mt_g[c * 624], sc[c].gen_idx);
         }
         // (the reference renumbers by first appearance on every apply_block_moves, also when nothing merged)
-        const int rc = which == 0 ? mc.agg_merge(diff_a, diff_b, nm) : mc.agg_merge_total(diff_a, nm);
-        if (rc != 0) {
-            cleanup();
-            return fail(h, BISBM_ERR_STATE,
-                        rc == -3 ? "chain %zu: agg_merge cannot reach the requested block counts (the reference would recurse without end)"
-                                 : "chain %zu: block renumbering inconsistent (the reference's sanity check, blockmodel.cc:605-609)",
-                        c);
-        }
-        if (c == 0) nka = mc.ka, nkb = mc.kb;
-        if (mc.ka != nka || mc.kb != nkb) {
-            cleanup();
-            return fail(h, BISBM_ERR_STATE,
-                        "chains ended with different block counts (chain 0: %zu+%zu, chain %zu: %zu+%zu); one (Ka,Kb) per handle",
-                        nka, nkb, c, mc.ka, mc.kb);
-        }
+        rcs[c] = which == 0 ? mc.agg_merge(diff_a, diff_b, nm) : mc.agg_merge_total(diff_a, nm);
+        if (rcs[c] != 0) return;
+        ends[c] = {mc.ka, mc.kb};
         for (size_t i = 0; i < 256; ++i) fmap[c * 256 + i] = mc.cmap[i] == 0xff ? 0 : mc.cmap[i];
         sc[c].merge_epoch = mc.epoch;
         if (compat) {
             store_mt(mc.engine, &mt_e[c * 624], sc[c].engine_idx);
             store_mt(mc.gen, &mt_g[c * 624], sc[c].gen_idx);
         }
+    };
+    {
+        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, std::thread::hardware_concurrency()), C / 4));
+        if (nt <= 1) {
+            for (size_t c = 0; c < C; ++c) one_chain(c);
+        } else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t)
+                th.emplace_back([&, t] {
+                    for (size_t c = t; c < C; c += nt) one_chain(c);
+                });
+            for (auto& x : th) x.join();
+        }
     }
+    for (size_t c = 0; c < C; ++c)
+        if (rcs[c] != 0) {
+            cleanup();
+            return fail(h, BISBM_ERR_STATE,
+                        rcs[c] == -3 ? "chain %zu: agg_merge cannot reach the requested block counts (the reference would recurse without end)"
+                                     : "chain %zu: block renumbering inconsistent (the reference's sanity check, blockmodel.cc:605-609)",
+                        c);
+        }
+    const size_t nka = ends[0].first, nkb = ends[0].second;
+    for (size_t c = 1; c < C; ++c)
+        if (ends[c] != ends[0]) {
+            cleanup();
+            return fail(h, BISBM_ERR_STATE,
+                        "chains ended with different block counts (chain 0: %zu+%zu, chain %zu: %zu+%zu); one (Ka,Kb) per handle",
+                        nka, nkb, c, ends[c].first, ends[c].second);
+        }
     MCHK(hipMemcpy(d_map, fmap.data(), fmap.size(), hipMemcpyHostToDevice));
     MCHK(launch_merge_relabel(h->d_labels, h->label_stride, (uint32_t)h->n, h->n_chains, d_map, h->stream));
     MCHK(hipMemcpy(h->d_scalars, sc.data(), sizeof(ChainScalars) * C, hipMemcpyHostToDevice));
