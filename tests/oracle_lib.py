@@ -91,6 +91,7 @@ def lib():
     L.orc_compute_dS_vertex.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]
     L.orc_transition_ratio.restype = C.c_double
     L.orc_transition_ratio.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, _f64p]
+    L.orc_pair_probe.argtypes = [C.c_void_p, C.c_uint64, C.c_double, _u64p]
     L.orc_propose_philox.restype = C.c_size_t
     L.orc_propose_philox.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_double]
     for name in ("orc_n", "orc_k", "orc_num_edges", "orc_max_degree"):
@@ -272,6 +273,14 @@ class OracleModel:
         acc = C.c_double(0)
         dS = self.L.orc_transition_ratio(self.h, v, s, C.byref(acc))
         return dS, acc.value
+
+    def pair_probe(self, sweeps, temperature=1.0):
+        """Runs `sweeps` Philox sweeps (exactly as anneal does) and reports how often the second step of a pass of the
+        production kernel stands: dict(steps, passes, second_stood, ...)."""
+        out = (C.c_uint64 * 6)()
+        self.L.orc_pair_probe(self.h, sweeps, temperature, out)
+        return dict(steps=out[0], passes=out[1], second_stood=out[2], first_moved=out[3], row_clashes=out[4],
+                    column_clashes=out[5])
 
     def propose_philox(self, v, u_idx, u_R, u_tgt):
         return self.L.orc_propose_philox(self.h, v, u_idx, u_R, u_tgt)

@@ -191,3 +191,27 @@ def test_chains_sample_exp_minus_S(mode, enum_pi):
     w = np.exp(-(S - S.min()) / 1.15)
     stat2, dof2, p2 = cases.chi_square(codes, states, w / w.sum())
     assert p2 < 1e-6, (stat2, dof2, p2)
+
+
+# ------------------------------------------------------------------ the rule behind "two steps per pass" 
+def test_second_step_of_a_pass_stands_when_the_rule_says_so():
+    """The production kernel evaluates steps q and q+1 against the state before step q and keeps step q+1's evaluation
+    unless step q moved its node and (a) the two steps share a block, or (b) step q has edges to the block t' of step
+    q+1's pivot AND step q+1's target lies strictly between step q's two blocks.  orc_pair_probe walks the chain
+    serially, applies that rule, and aborts if a proposal it declared untouched differs after step q -- so reaching
+    the end proves the rule on this run; the chain it produced must be the chain anneal() produces."""
+    na = nb = 6000
+    rowptr, col = cases.random_graph(4, na, nb, 120_000, 16, 16)
+    lab = O.contiguous_labels(na, nb, 16, 16)
+    probe = O.OracleModel(rowptr, col, na, nb, 16, 16, 1.0, lab)
+    plain = O.OracleModel(rowptr, col, na, nb, 16, 16, 1.0, lab)
+    for m in (probe, plain):
+        m.seed_philox(3, 1)
+        m.shuffle_bisbm()
+    st = probe.pair_probe(3)
+    plain.anneal("constant", [1.0], 3 * (na + nb), 1 << 60)
+    assert (probe.memberships() == plain.memberships()).all() and (probe.m() == plain.m()).all()
+    assert st["steps"] == 3 * (na + nb)
+    stood = st["second_stood"] / st["passes"]
+    print("passes %d, second step stood in %.1f %%, %.2f steps per pass" % (st["passes"], 100 * stood, st["steps"] / (st["passes"] + (st["steps"] - st["passes"] - st["second_stood"]))))
+    assert 0.5 < stood < 1.0 and st["row_clashes"] > 0 and st["column_clashes"] > 0
