@@ -1210,6 +1210,87 @@ void orc_pair_probe(orc_model *m, uint64_t sweeps, double temperature, uint64_t 
     free(kv_a);
 }
 
+/* Diagnostic, like orc_pair_probe but for passes of up to `depth` (<= 8) steps: step q+j of a pass stands when every
+ * step before it in the pass that moved its node left its inputs alone (rows: block sets disjoint; column t': no edges
+ * to it, or the target outside the moved span); a pass ends at the first step that does not stand.  out[0] = steps,
+ * out[1] = passes, out[2 + j] = passes that committed exactly j + 1 steps.  The chain is anneal()'s. */
+void orc_depth_probe(orc_model *m, uint64_t sweeps, double temperature, int depth, uint64_t out[12]) {
+    size_t n = m->n, K = m->K;
+    if (depth < 1) depth = 1;
+    if (depth > 8) depth = 8;
+    int *kv_hist = (int *)malloc(sizeof(int) * K * 8);
+    memset(out, 0, sizeof(uint64_t) * 12);
+    for (uint64_t sw = 0; sw < sweeps; ++sw) {
+        uint32_t keys[2][4];
+        phx_draw(m->phx_seed, m->phx_chain, PHX_SWEEP_KEY, 2 * m->sweeps_total, keys[0]);
+        phx_draw(m->phx_seed, m->phx_chain, PHX_SWEEP_KEY, 2 * m->sweeps_total + 1, keys[1]);
+        for (int ph = 0; ph < 2; ++ph) {
+            size_t n_own = ph ? m->nb : m->na, base = ph ? m->na : 0;
+            for (size_t c0 = 0; c0 < n_own; c0 += 64) {
+                size_t cnt = n_own - c0 < 64 ? n_own - c0 : 64;
+                size_t q = 0;
+                while (q < cnt) {
+                    size_t d = cnt - q < (size_t)depth ? cnt - q : (size_t)depth;
+                    size_t rj[8], sj[8], tj[8];
+                    int uses_col[8];
+                    for (size_t j = 0; j < d; ++j) { /* every step of the pass proposed on the state before the pass */
+                        size_t vj = base + tiled_perm(keys[ph], (uint32_t)n_own, (uint32_t)(c0 + q + j));
+                        uint64_t gs = m->sweeps_total * n + base + c0 + q + j;
+                        uint32_t A[4], B[4];
+                        phx_draw(m->phx_seed, m->phx_chain, PHX_STEP_A, gs, A);
+                        phx_draw(m->phx_seed, m->phx_chain, PHX_STEP_B, gs, B);
+                        rj[j] = m->labels[vj];
+                        sj[j] = propose_philox(m, vj, u53(A[0], A[1]), u53(A[2], A[3]), u53(B[0], B[1]));
+                        size_t dg = (size_t)m->deg[vj];
+                        uses_col[j] = dg != 0;
+                        tj[j] = 0;
+                        if (dg) {
+                            size_t which = (size_t)(u53(A[0], A[1]) * (double)dg);
+                            if (which >= dg) which = dg - 1;
+                            tj[j] = m->labels[m->col[m->rowptr[vj] + which]];
+                        }
+                    }
+                    size_t committed = 0;
+                    size_t mr[8], ms[8];
+                    int moved[8];
+                    for (size_t j = 0; j < d; ++j) {
+                        int stands = 1;
+                        for (size_t i = 0; i < j && stands; ++i) {
+                            if (!moved[i]) continue;
+                            size_t lo = mr[i] < ms[i] ? mr[i] : ms[i], hi = mr[i] < ms[i] ? ms[i] : mr[i];
+                            if (rj[j] == mr[i] || rj[j] == ms[i] || sj[j] == mr[i] || sj[j] == ms[i]) stands = 0;
+                            else if (uses_col[j] && kv_hist[i * K + tj[j]] != 0 && sj[j] > lo && sj[j] < hi) stands = 0;
+                        }
+                        if (!stands) break;
+                        size_t vj = base + tiled_perm(keys[ph], (uint32_t)n_own, (uint32_t)(c0 + q + j));
+                        uint64_t gs = m->sweeps_total * n + base + c0 + q + j;
+                        compute_kv(m, vj);
+                        memcpy(kv_hist + j * K, m->kv, sizeof(int) * K);
+                        size_t r0 = m->labels[vj];
+                        if (j > 0) { /* the claim: the proposal made before the pass is the proposal now */
+                            uint32_t A[4], B[4];
+                            phx_draw(m->phx_seed, m->phx_chain, PHX_STEP_A, gs, A);
+                            phx_draw(m->phx_seed, m->phx_chain, PHX_STEP_B, gs, B);
+                            if (propose_philox(m, vj, u53(A[0], A[1]), u53(A[2], A[3]), u53(B[0], B[1])) != sj[j] || r0 != rj[j]) abort();
+                        }
+                        int ok = step_philox(m, vj, temperature, gs);
+                        moved[j] = ok && m->labels[vj] != r0;
+                        mr[j] = r0;
+                        ms[j] = m->labels[vj];
+                        ++committed;
+                    }
+                    out[0] += committed;
+                    out[1] += 1;
+                    out[2 + committed - 1] += 1;
+                    q += committed;
+                }
+            }
+        }
+        m->sweeps_total++;
+    }
+    free(kv_hist);
+}
+
 /* metropolis_hasting.cc:64-101 */
 double orc_anneal(orc_model *m, int schedule, float kw0, float kw1, uint64_t duration,
                   uint64_t steps_await) {

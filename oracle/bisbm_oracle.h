@@ -103,6 +103,7 @@ double orc_compute_dS_vertex(orc_model *m, size_t v, size_t r, size_t s); /* blo
 double orc_transition_ratio(orc_model *m, size_t v, size_t s, double *accu_r);
 /* diagnostic: how often two consecutive steps of a chunk are independent (see the .c file) */
 void orc_pair_probe(orc_model *m, uint64_t sweeps, double temperature, uint64_t out[6]);
+void orc_depth_probe(orc_model *m, uint64_t sweeps, double temperature, int depth, uint64_t out[12]);
 /* the Philox-mode proposal (single_vertex_change, blockmodel.cc:613-637) for given uniforms */
 size_t orc_propose_philox(orc_model *m, size_t v, double u_idx, double u_R, double u_tgt);
 

@@ -92,6 +92,7 @@ def lib():
     L.orc_transition_ratio.restype = C.c_double
     L.orc_transition_ratio.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, _f64p]
     L.orc_pair_probe.argtypes = [C.c_void_p, C.c_uint64, C.c_double, _u64p]
+    L.orc_depth_probe.argtypes = [C.c_void_p, C.c_uint64, C.c_double, C.c_int, _u64p]
     L.orc_propose_philox.restype = C.c_size_t
     L.orc_propose_philox.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_double]
     for name in ("orc_n", "orc_k", "orc_num_edges", "orc_max_degree"):
@@ -281,6 +282,12 @@ class OracleModel:
         self.L.orc_pair_probe(self.h, sweeps, temperature, out)
         return dict(steps=out[0], passes=out[1], second_stood=out[2], first_moved=out[3], row_clashes=out[4],
                     column_clashes=out[5])
+
+    def depth_probe(self, sweeps, depth, temperature=1.0):
+        """Like pair_probe for passes of up to `depth` steps: (steps, passes, [share of passes committing j + 1 steps])."""
+        out = (C.c_uint64 * 12)()
+        self.L.orc_depth_probe(self.h, sweeps, temperature, depth, out)
+        return out[0], out[1], [out[2 + j] / max(out[1], 1) for j in range(depth)]
 
     def propose_philox(self, v, u_idx, u_R, u_tgt):
         return self.L.orc_propose_philox(self.h, v, u_idx, u_R, u_tgt)

@@ -215,3 +215,10 @@ def test_second_step_of_a_pass_stands_when_the_rule_says_so():
     stood = st["second_stood"] / st["passes"]
     print("passes %d, second step stood in %.1f %%, %.2f steps per pass" % (st["passes"], 100 * stood, st["steps"] / (st["passes"] + (st["steps"] - st["passes"] - st["second_stood"]))))
     assert 0.5 < stood < 1.0 and st["row_clashes"] > 0 and st["column_clashes"] > 0
+    # the same rule composed over deeper passes (what a four-steps-per-pass kernel would rest on): still the serial chain
+    deep = O.OracleModel(rowptr, col, na, nb, 16, 16, 1.0, lab)
+    deep.seed_philox(3, 1)
+    deep.shuffle_bisbm()
+    steps, passes, share = deep.depth_probe(3, 4)
+    assert steps == 3 * (na + nb) and (deep.memberships() == plain.memberships()).all()
+    assert abs(sum(share) - 1) < 1e-9 and steps / passes > st["steps"] / (st["passes"] + (st["steps"] - st["passes"] - st["second_stood"]))
