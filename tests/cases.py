@@ -39,6 +39,9 @@ CASES = [
     ("mid_tier_low", 2400, 2400, 28800, 2, 2, 1.0, 0, 0),
     # ... and a dense graph (mean degree 40, blocks of 1000 nodes): k / sqrt(n) around 5, the low converged tier
     ("dense_low_tier", 2000, 2000, 80000, 2, 2, 1.0, 0, 0),
+    # K = 32 + 32 with a hub of degree 600: eta (64 x 601 words) does not fit the LDS budget and stays in HBM while the
+    # K <= 32 kernel evaluates two steps per pass
+    ("k32_eta_in_hbm", 3000, 3000, 60000, 32, 32, 1.0, 1, 0),
     # epsilon = 0 (legal in the reference: -E 0): no uniform component in the proposal, denominators m_r[t] alone
     ("eps0", 300, 200, 3000, 5, 7, 0.0, 0, 4),
     ("eps0_direct", 20000, 20000, 100000, 2, 2, 0.0, 0, 0),
