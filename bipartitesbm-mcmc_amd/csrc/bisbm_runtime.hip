@@ -1344,6 +1344,7 @@ int run_split(bisbm_engine* h, int type, int nm) {
     else
         h->ka += 1;
     h->K = h->ka + h->kb;
+    h->state_ready = false;  // (until the rebuild below has run: a failed allocation must not leave a usable-looking handle)
     if (h->ka > h->cap_ka || h->kb > h->cap_kb) {
         h->cap_ka = std::max(h->cap_ka, h->ka);
         h->cap_kb = std::max(h->cap_kb, h->kb);
