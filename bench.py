@@ -62,6 +62,8 @@ def parse_args(argv=None):
                     help="skip the extra legs after the timed region (equilibrated-start figure, pooling timings)")
     ap.add_argument("--shuffle-ids", action="store_true",
                     help="custom workload: renumber the nodes of each type at random (ids that carry no structure)")
+    ap.add_argument("--planted-start", action="store_true",
+                    help="custom workload: start every chain on the generator's planted partition instead of a randomised one")
     ap.add_argument("--no-reorder", action="store_true",
                     help="with --shuffle-ids: do not run the ingest-time locality reordering pass")
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)  # internal: one CPU-baseline process
@@ -289,7 +291,11 @@ def main():
     model = pkg.BlockModel(labels, syn.types_vector(na, nb), ka + kb, ka, kb, 1.0, (rowptr, col),
                            n_chains=shard.n_local, rng="philox", seed=20240229, device=device_index,
                            first_chain_id=shard.first_chain_id)
-    model.shuffle_bisbm()  # --randomize start
+    if args.planted_start:
+        model.set_memberships(planted)
+        model.init_bisbm()
+    else:
+        model.shuffle_bisbm()  # --randomize start
     mh = pkg.MetropolisHasting()
 
     def sync():
@@ -398,7 +404,8 @@ def main():
         avg_kernel_s = kernel_ms / max(args.steps, 1) / 1e3
         balg = b_alg_per_update(n, E)
         achieved = balg * per_launch_updates / avg_kernel_s / 1e9
-        default_cfg = (na, nb, E, ka, kb, args.chains) == (500_000, 500_000, 10_000_000, 32, 32, 1024) and not args.shuffle_ids
+        default_cfg = ((na, nb, E, ka, kb, args.chains) == (500_000, 500_000, 10_000_000, 32, 32, 1024) and not args.shuffle_ids
+                       and not args.planted_start)
         # HBM bytes per launch and instructions per update from the PMC passes committed under profiles/ (rocprofv3
         # --pmc, separate runs of this same command); only quoted for the workload they were measured on
         traffic, traffic_src, issue, steady = None, None, None, None
@@ -447,7 +454,7 @@ def main():
             "config": {
                 "workload": ("BASELINE configs[2]: " if default_cfg else "custom: ")
                 + "planted bipartite N_a=%d N_b=%d E=%d Ka=%d Kb=%d, %d chains/GPU, constant T=1, eps=1, "
-                  "randomised start, Philox mode%s" % (na, nb, E, ka, kb, args.chains,
+                  "%s start, Philox mode%s" % (na, nb, E, ka, kb, args.chains, "planted-partition" if args.planted_start else "randomised",
                                                        (", node ids renumbered at random" +
                                                         (", locality reordering at ingest (%.1f s)" % reorder_s if reorder else ""))
                                                        if args.shuffle_ids else ""),
