@@ -231,8 +231,12 @@ struct TiledOrder {
     uint32_t n;
     __device__ __forceinline__ void init(U4 keys, uint32_t n_) {
         n = n_;
-        tiles.init(keys, (n_ + (1u << kTileBits) - 1u) >> kTileBits);
-        cells.init(U4{keys.y, keys.z, keys.w, keys.x}, 1u << (kTileBits - kCellBits));
+        const uint32_t n_tiles = (n_ + (1u << kTileBits) - 1u) >> kTileBits;
+        tiles.init(keys, n_tiles);
+        // a class that fits one tile has only the cells it needs: the padded domain is then less than 64 ids larger than
+        // the class instead of 4096 (cycle walking over 4096 positions for 18 nodes was the cost of a tiny graph's step)
+        cells.init(U4{keys.y, keys.z, keys.w, keys.x},
+                   n_tiles == 1u ? (n_ + (1u << kCellBits) - 1u) >> kCellBits : 1u << (kTileBits - kCellBits));
         inner.init(U4{keys.z, keys.w, keys.x, keys.y}, 1u << kCellBits);
     }
     __device__ __forceinline__ uint32_t operator()(uint32_t i) const {
@@ -695,6 +699,14 @@ __device__ inline double log_q_approx(const Tables& t, unsigned long long n, uns
     const double lf = log(v) - log1p(-exp(-v) * (1 + u * u / 2)) / 2 - log(2.) * 3 / 2. - log(u) - log(kPi);
     const double g = 2 * v / u - u * log1p(-exp(-v));
     return lf - log((double)n) + sq * g;
+}
+
+// log_q for n <= 10000 straight from the table (int_part.hh:27-37 with k already min(k, n)): the same entries log_q()
+// returns, without the tier ladder around them -- the only tier a graph with at most 10^4 edges ever uses
+__device__ __forceinline__ double log_q_table(const Tables& t, int n, int k_min) {
+    if (n <= 0 || k_min < 1) return 0;
+    if ((uint32_t)k_min >= t.q_stride) return NAN;  // outside the uploaded columns (cannot happen on the sweep path)
+    return t.q[(size_t)n * t.q_stride + (size_t)k_min];
 }
 
 // logn_pre: log(n) from the host table when the caller has it already (FAST only), else unused

@@ -212,8 +212,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     const uint32_t n = p.n;
     const uint64_t all_sweeps = p.duration / n;
     const double T_const = (double)p.kw0;  // CT: constant schedule (metropolis_hasting.cc:25-28)
-    // m_r <= E: with E + maxdeg inside the log_q table no step can use the closed-form tier of the hot path
-    const bool never_direct = (p.rowptr[n] >> 1) + p.maxdeg <= (uint32_t)kQNmax;
     // the early-stop bookkeeping can only ever fire below T = 1, and only if steps_await can be reached within the call
     // (the counter starts at 0 and gains at most 1 per step) -- a scalar word, not a lane mask: one s_cmp to test
     // two steps per pass (step_pair): K <= 32 (a constant schedule at T = 0 takes the general step anyway);
@@ -400,8 +398,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 const uint32_t tloc_l = ((uint32_t)piv_l - oth_base) & 63u;
                 const uint32_t rloc_l = r_l - own_base;
                 uint32_t prop_l = draw_target(__builtin_amdgcn_ds_bpermute((int)(tloc_l << 2), mr_oth), ud_R, ud_tgt);
-                if (k_own == 1u || deg_l == 0u || deg_l > kRowCap || (CT && T_const == 0.) || never_direct)
-                    prop_l |= 0x80000000u;
+                if (k_own == 1u || deg_l == 0u || deg_l > kRowCap || (CT && T_const == 0.)) prop_l |= 0x80000000u;
 
                 // anneal()'s bookkeeping, metropolis_hasting.cc:85-94, see emin_l0 above
                 const unsigned long long below1_mask =
@@ -650,6 +647,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                             double sq, rr;
                             sqrt_rsqrt(nd, sq, rr);
                             lq = log_q_closed(kd, sq, rr, logn, lqc);
+                        } else if (__builtin_amdgcn_ballot_w64(qn > kQNmax) == 0) {
+                            lq = log_q_table(tab, qn, qk2);  // small graphs: every argument inside the table
                         } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= c_169 * nd)) == 0) {
                             double sq, rr;  // u >= 13 everywhere: second-order closed form (also right for u > 24)
                             sqrt_rsqrt(nd, sq, rr);
@@ -821,6 +820,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                             double sq, rr;
                             sqrt_rsqrt(nd, sq, rr);
                             lq = log_q_closed(kd, sq, rr, logn, lqc);
+                        } else if (__builtin_amdgcn_ballot_w64(qn > kQNmax) == 0) {
+                            lq = log_q_table(tab, qn, qk2);  // small graphs: every argument inside the table (int_part.hh:27-37)
                         } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= c_169 * nd)) == 0) {
                             // u >= 13 in every lane (blocks of a few thousand nodes): the second-order closed form, which
                             // also serves the lanes with u > 24

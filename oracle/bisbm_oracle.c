@@ -463,11 +463,14 @@ static uint32_t feistel_perm(const uint32_t keys[4], uint32_t n, uint32_t i) {
  * labels from the same neighbourhoods and read adjacent CSR rows); cycle walking over the padded domain. */
 static uint32_t tiled_perm(const uint32_t keys[4], uint32_t n, uint32_t i) {
     const uint32_t ntiles = (n + 4095u) >> 12;
+    /* a class that fits one tile has only the cells it needs (ceil(n / 64) of them): the padded domain is then less than
+     * 64 ids larger than the class instead of 4096 (the reference's own data sets have 14..500 nodes per type) */
+    const uint32_t ncells = ntiles == 1 ? (n + 63u) >> 6 : 64u;
     uint32_t x = i;
     do {
         uint32_t t = feistel_perm(keys, ntiles, x >> 12);
         uint32_t k2[4] = {keys[1] ^ (t * 0x9E3779B9u), keys[2], keys[3], keys[0]};
-        uint32_t c = feistel_perm(k2, 64u, (x >> 6) & 63u);
+        uint32_t c = feistel_perm(k2, ncells, (x >> 6) & 63u);
         uint32_t k3[4] = {keys[2] ^ (((t << 6) | c) * 0x85EBCA6Bu), keys[3], keys[0], keys[1]};
         x = (t << 12) | (c << 6) | feistel_perm(k3, 64u, x & 63u);
     } while (x >= n);

@@ -141,9 +141,8 @@ def test_philox_proposal_distribution_is_the_references(graph, ka, kb, eps):
 # ------------------------------------------------------------------ stationary distribution on an enumerable graph
 N_CHAINS = 24000
 BURN_IN = 40
-# (the Philox oracle is slow on a 6-node class: the id-local visit order cycle-walks a 4096-entry padded domain)
-N_CHAINS_PHILOX = 8000
-BURN_IN_PHILOX = 30
+N_CHAINS_PHILOX = 24000
+BURN_IN_PHILOX = 40
 
 
 def _oracle_samples(mode, n_chains, burn_in):
