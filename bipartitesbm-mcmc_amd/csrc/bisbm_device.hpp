@@ -258,13 +258,31 @@ struct TiledOrder {
 // ------------------------------------------------------------------------------------------
 // std::mt19937 + libstdc++-11 distributions, state in LDS (compat mode)
 // ------------------------------------------------------------------------------------------
+// Every member and mt_shuffle are force-inlined: one out-of-line call taking the engine by reference would pin the
+// whole struct (pointers and position) in scratch memory for the kernel's lifetime -- a vector-memory round trip per
+// draw on a lone wave (measured: 3.4 us per compat step, most of it those round trips).
 struct Mt {
     uint32_t* mt;  // 624 words in LDS
     int idx;       // wave-uniform
+    uint32_t* tm = nullptr;  // optional, 624 words in LDS: the tempered outputs of mt[], so that a draw is one LDS read
+                             // (the sweep kernel draws ~10 words per step; the state that is saved stays mt[] alone)
 
+    static __device__ __forceinline__ uint32_t temper(uint32_t y) {
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= (y >> 18);
+        return y;
+    }
+    // fill tm[] from mt[] (after loading a saved state)
+    __device__ __forceinline__ void retemper() {
+        for (int k = lane_id(); k < 624; k += kWave) tm[k] = temper(mt[k]);
+        __syncthreads();
+    }
     // regenerate all 624 words; chunks of 64 lanes, reads of a chunk complete before its writes
-    __device__ void twist() {
+    __device__ __forceinline__ void twist() {
         const int lane = lane_id();
+#pragma nounroll
         for (int c = 0; c < 624; c += kWave) {
             const int k = c + lane;
             uint32_t v = 0;
@@ -273,30 +291,45 @@ struct Mt {
                 v = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
             }
             __syncthreads();
-            if (k < 624) mt[k] = v;
+            if (k < 624) {
+                mt[k] = v;
+                if (tm) tm[k] = temper(v);
+            }
             __syncthreads();
         }
         idx = 0;
     }
-    __device__ uint32_t next() {
+    __device__ __forceinline__ uint32_t next() {
         if (idx >= 624) twist();
-        uint32_t y = mt[idx++];
-        y ^= (y >> 11);
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= (y >> 18);
-        return y;
+        if (tm) return tm[idx++];
+        return temper(mt[idx++]);
     }
     // uniform_real_distribution<double>(0,1) -> generate_canonical<double,53> (random.tcc:3348-3384)
-    __device__ double canonical() {
-        const double x0 = (double)next();
-        const double x1 = (double)next();
-        double r = (x0 + x1 * 4294967296.0) / 18446744073709551616.0;
+    static __device__ __forceinline__ double canonical_of(uint32_t w0, uint32_t w1) {
+        double r = ((double)w0 + (double)w1 * 4294967296.0) / 18446744073709551616.0;
         if (r >= 1.0) r = 0x1.fffffffffffffp-1;  // nextafter(1, 0)
         return r;
     }
+    __device__ __forceinline__ double canonical() {
+        if (tm && idx + 2 <= 624) {  // both words in one LDS round trip
+            const uint32_t w0 = tm[idx], w1 = tm[idx + 1];
+            idx += 2;
+            return canonical_of(w0, w1);
+        }
+        const uint32_t w0 = next();
+        const uint32_t w1 = next();
+        return canonical_of(w0, w1);
+    }
+    // The next four canonical() values at once, value p in every lane with (lane & 3) == p: one LDS round trip for all
+    // the uniforms a step can draw from this engine.  Only when no regeneration falls inside (idx + 8 <= 624); the
+    // caller advances idx by two words per value it consumed.
+    __device__ __forceinline__ bool window4_ok() const { return tm != nullptr && idx + 8 <= 624; }
+    __device__ __forceinline__ double window4() const {
+        const int p = lane_id() & 3;
+        return canonical_of(tm[idx + 2 * p], tm[idx + 2 * p + 1]);
+    }
     // Lemire downscale for a 32-bit URBG (uniform_int_dist.h:245-272)
-    __device__ uint32_t lemire(uint32_t range) {
+    __device__ __forceinline__ uint32_t lemire(uint32_t range) {
         uint64_t product = (uint64_t)next() * (uint64_t)range;
         uint32_t low = (uint32_t)product;
         if (low < range) {
@@ -313,7 +346,7 @@ struct Mt {
 // std::shuffle (stl_algo.h:3729-3793) of v[0..n) with wave-uniform control flow.  T is uint32_t
 // (vlist) or uint8_t (labels).  Every lane computes the same indices; lane 0 stores.
 template <class T>
-__device__ void mt_shuffle(Mt& g, T* v, uint32_t n) {
+__device__ __forceinline__ void mt_shuffle(Mt& g, T* v, uint32_t n) {
     if (n == 0) return;
     const int lane = lane_id();
     auto swap_at = [&](uint32_t i, uint32_t j) {

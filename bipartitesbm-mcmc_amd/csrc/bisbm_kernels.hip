@@ -28,6 +28,24 @@
 
 namespace bisbm {
 
+// Diagnostic build only (-DBISBM_GSTAMPS): s_memtime per stage of the generic kernel's step, summed per launch.
+#ifdef BISBM_GSTAMPS
+__device__ unsigned long long g_generic_stamps[16];
+#define GSTAMP(c, i)                                                                     \
+    do {                                                                                 \
+        unsigned long long now_;                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        __asm__ volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        (c).st_acc[i] += now_ - (c).st_prev;                                             \
+        (c).st_prev = now_;                                                              \
+    } while (0)
+#else
+#define GSTAMP(c, i) \
+    do {             \
+    } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // per-chain context held in registers / LDS while a sweep kernel runs
 // ------------------------------------------------------------------------------------------
@@ -49,6 +67,10 @@ struct ChainCtx {
     // MH object state
     double cum_dS;
     double accu_r;
+#ifdef BISBM_GSTAMPS
+    unsigned long long st_acc[10];
+    unsigned long long st_prev;
+#endif
 };
 
 // eta lives in LDS or in HBM, chosen at compile time (template EL): one generic pointer would turn the
@@ -99,6 +121,7 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
     const uint32_t own_base = type_b ? c.ka : 0, oth_base = type_b ? 0 : c.ka;
     const uint32_t r_loc = r - own_base;
     *s_out = r;
+    GSTAMP(c, 1);
 
     // ---- k_v: neighbour-label histogram of the CSR row (replaces the dense k_[v] row of
     //      blockmodel.cc:691-700), reduced in LDS ----
@@ -108,10 +131,19 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
     for (uint32_t j = kWave + lane; j < deg; j += kWave)  // rows longer than one wave (rare)
         atomicAdd(&c.hist[(int)c.labels[p.col[beg + j]] - (int)oth_base], 1);
     wave_fence();
+    GSTAMP(c, 2);
 
     // ---- proposal: single_vertex_change, blockmodel.cc:613-637 ----
     uint32_t s;
     double u_acc = 0.;
+    const bool win_ok = (RNG == RNG_COMPAT) && engine.window4_ok();
+    double win = 0.;
+    uint32_t win_used = 0;
+    if (RNG == RNG_COMPAT && win_ok) win = engine.window4();
+    auto draw_engine = [&]() -> double {
+        if (win_ok) return readlane(win, win_used++);
+        return engine.canonical();
+    };
     if (RNG == RNG_PHILOX) {
 #if defined(BISBM_ABLATE) && (BISBM_ABLATE & 2)
         const uint32_t hsh = mix32((uint32_t)gstep ^ chain_gid);  // diagnostic build: Philox removed
@@ -159,19 +191,21 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
         }
     } else {
         // the reference's draw order: engine for idx / R / uniform target,
-        // `gen` for the discrete draw
+        // `gen` for the discrete draw.  size_t(u * K), size_t(u * deg): the products are below 2^32, so the conversion
+        // to uint32_t (one instruction; there is no f64 -> u64 one) truncates to the same integer.  The (at most four) uniforms a step takes from `engine` come out of one
+        // lane-parallel read of its tempered words whenever no regeneration falls inside the step.
         if (k_own == 1) {
             s = r;
         } else if (deg == 0) {
-            s = (uint32_t)(size_t)(engine.canonical() * (double)K);
+            s = (uint32_t)(draw_engine() * (double)K);
         } else {
-            const uint32_t which = (uint32_t)(size_t)(engine.canonical() * (double)deg);
+            const uint32_t which = (uint32_t)(draw_engine() * (double)deg);
             const uint32_t t = which < (uint32_t)kWave ? (uint32_t)readlane(lab_reg, which)
                                                         : (uint32_t)c.labels[p.col[beg + which]];
             const int32_t mrt = c.mr[t];
             const double R_t = c.epsilon * (double)K / (mrt + c.epsilon * (double)K);
-            if (engine.canonical() < R_t) {
-                s = (uint32_t)(size_t)(engine.canonical() * (double)K);
+            if (draw_engine() < R_t) {
+                s = (uint32_t)(draw_engine() * (double)K);
             } else {
                 // std::discrete_distribution over the full row m_[t][0..K) (random.tcc:2656-2714):
                 // p = w / sum, serial partial sums, last = 1.0, lower_bound(u)
@@ -186,12 +220,13 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
                     int32_t w = 0;
                     if (g < K && g >= own_base && g < own_base + k_own) w = Mx(c, type_b, g - own_base, t_loc);
                     const double pr = (double)w / sum;
-                    double cp = 0.;
-                    const uint32_t cnt = (K - c0) < (uint32_t)kWave ? (K - c0) : (uint32_t)kWave;
-                    for (uint32_t jj = 0; jj < cnt; ++jj) {
-                        const double pj = readlane(pr, jj);
-                        acc = (c0 + jj == 0) ? pj : acc + pj;
-                        if ((uint32_t)lane == jj) cp = acc;
+                    // partial sums in index order; a zero weight adds +0.0 (the sum keeps its bits), so only the
+                    // non-zero entries take a serial step and every lane keeps the sum up to its own index
+                    double cp = acc;
+                    for (unsigned long long nz = __ballot(w != 0); nz; nz &= nz - 1) {
+                        const uint32_t jj = (uint32_t)__builtin_ctzll(nz);
+                        acc = acc + readlane(pr, jj);
+                        if ((uint32_t)lane >= jj) cp = acc;
                     }
                     if (g == K - 1) cp = 1.0;
                     const unsigned long long hit = __ballot(g < K && cp >= u);
@@ -204,6 +239,7 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
         }
     }
     *s_out = s;
+    GSTAMP(c, 3);
 
     // ---- transition_ratio, metropolis_hasting.cc:103-192 ----
     double dS;
@@ -276,6 +312,7 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
         const double lq = log_q<RNG == RNG_PHILOX>(tab, qn, qk, (RNG == RNG_PHILOX && qn > 0 && (uint64_t)qn < tab.lg_size) ? tab.logtab[qn] : 0.);
 #endif
 
+        GSTAMP(c, 4);
         // (3) sums over opposite-type blocks (:150-163)
         double accu0 = 0., accu1 = 0., entropy0 = 0., entropy1 = 0.;
         for (uint32_t c0 = 0; c0 < k_oth; c0 += kWave) {
@@ -294,10 +331,10 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
                     A0 = t.k * (t.m_st + eps) / (t.mr_t + eps * Kd) / ideg;
                     A1 = t.k * (t.m_rt - t.k + eps) / (t.mr_t + eps * Kd) / ideg;
                 }
-                // the reference's serial sums in ascending block index
-                const uint32_t cnt = (k_oth - c0) < (uint32_t)kWave ? (k_oth - c0) : (uint32_t)kWave;
-                for (uint32_t jj = 0; jj < cnt; ++jj) {
-                    if (readlane(t.k, jj) == 0) continue;
+                // the reference's serial sums in ascending block index: only blocks with k != 0 contribute (:152), so
+                // walk the set bits of that mask (lanes past k_oth hold k = 0)
+                for (unsigned long long nz = __ballot(t.k != 0); nz; nz &= nz - 1) {
+                    const uint32_t jj = (uint32_t)__builtin_ctzll(nz);
                     accu0 += readlane(A0, jj);
                     accu1 += readlane(A1, jj);
                     entropy0 -= readlane(t.L1, jj);
@@ -335,6 +372,7 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
         }
     }
 
+    GSTAMP(c, 5);
     // ---- accept, metropolis_hasting.cc:47-61 ----
     bool accept;
     if (RNG == RNG_PHILOX) {
@@ -348,21 +386,30 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
         accept = dS < 0;
     } else {
         const double a = -1. / T * dS + log(c.accu_r);
-        accept = (a > 0.) ? true : (engine.canonical() < exp(a));
+        accept = (a > 0.) ? true : (draw_engine() < exp(a));
     }
+    if (RNG == RNG_COMPAT && win_ok) engine.idx += 2 * (int)win_used;
+    GSTAMP(c, 6);
     if (!accept) return false;
 
     // ---- apply_mcmc_moves, blockmodel.cc:461-503 ----
     if (c.nr[r] - 1 == 0) return false;  // :467-471: a move that empties a block is vetoed after the draw
     if (same) return true;               // n_r, eta, m updates cancel; entropy_ += 0
     wave_fence();                        // all lanes have read nr/mr/eta before lane 0 rewrites them
+    // the counters are updated with LDS / memory atomics that return nothing: fire and forget, where a read-modify-write
+    // in C++ would be six dependent round trips on lane 0
     if (lane == 0) {
-        c.nr[r] -= 1;
-        c.nr[s] += 1;
-        eta_store<EL>(c, r * c.D + deg, eta_load<EL>(c, r * c.D + deg) - 1u);
-        eta_store<EL>(c, s * c.D + deg, eta_load<EL>(c, s * c.D + deg) + 1u);
-        c.mr[r] -= (int)deg;
-        c.mr[s] += (int)deg;
+        atomicSub(&c.nr[r], 1);
+        atomicAdd(&c.nr[s], 1);
+        if constexpr (EL) {
+            atomicSub(&c.eta_l[r * c.D + deg], 1u);
+            atomicAdd(&c.eta_l[s * c.D + deg], 1u);
+        } else {
+            atomicSub(&c.eta_g[r * c.D + deg], 1u);
+            atomicAdd(&c.eta_g[s * c.D + deg], 1u);
+        }
+        atomicSub(&c.mr[r], (int)deg);
+        atomicAdd(&c.mr[s], (int)deg);
         c.labels[v] = (uint8_t)s;
     }
     {
@@ -370,13 +417,14 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
         for (uint32_t j = lane; j < k_oth; j += kWave) {  // :479-487 (mirror entries are the same cells here)
             const int k = c.hist[j];
             if (k != 0) {
-                Mx(c, type_b, r_loc, j) -= k;
-                Mx(c, type_b, s_loc, j) += k;
+                atomicSub(&Mx(c, type_b, r_loc, j), k);
+                atomicAdd(&Mx(c, type_b, s_loc, j), k);
             }
         }
     }
     c.cum_dS += dS;  // :500
     wave_fence();
+    GSTAMP(c, 7);
     return true;
 }
 
@@ -425,6 +473,10 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
         cur += sizeof(uint32_t) * 624;
         gen.mt = (uint32_t*)cur;
         cur += sizeof(uint32_t) * 624;
+        engine.tm = (uint32_t*)cur;  // tempered outputs beside both states
+        cur += sizeof(uint32_t) * 624;
+        gen.tm = (uint32_t*)cur;
+        cur += sizeof(uint32_t) * 624;
         if (p.vlist_in_lds) {
             vl = (uint32_t*)cur;
             cur += sizeof(uint32_t) * p.n;
@@ -469,8 +521,16 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
     }
     c.cum_dS = sc->cum_dS;
     c.accu_r = sc->accu_r;
+#ifdef BISBM_GSTAMPS
+    for (int i = 0; i < 10; ++i) c.st_acc[i] = 0;
+    __asm__ volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c.st_prev)::"memory");
+#endif
     uint64_t sweeps_total = sc->sweeps_total;
     __syncthreads();
+    if (RNG == RNG_COMPAT) {
+        engine.retemper();
+        gen.retemper();
+    }
 
     Tables tab{p.lgamma_tab, p.lgamma_size, p.q_tab, p.q_stride, p.log_tab};
     const uint32_t chain_gid = p.first_chain_id + chain;
@@ -483,7 +543,9 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
     for (uint64_t sweep = 0; sweep < all_sweeps; ++sweep) {
         TiledOrder order_a, order_b;  // Philox mode: all type-a nodes, then all type-b nodes, each class permuted
         if (RNG == RNG_COMPAT) {
+            GSTAMP(c, 1);
             mt_shuffle(engine, vl, (uint32_t)num_nodes);  // :80
+            GSTAMP(c, 0);
         } else {
             order_a.init(phx_draw(p.seed, chain_gid, PHX_SWEEP_KEY, 2 * sweeps_total), p.na);
             order_b.init(phx_draw(p.seed, chain_gid, PHX_SWEEP_KEY, 2 * sweeps_total + 1), p.nb);
@@ -533,6 +595,7 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
             gather(0, nb1, lab1);
             gather(1, nb2, lab2);
             gather(2, nb3, lab3);
+            GSTAMP(c, 8);
             const uint32_t kNoMove = 0xFFFFFFFEu;
             uint32_t mv_v1 = kNoMove, mv_v2 = kNoMove, mv_v3 = kNoMove;  // moves of steps q-3, q-2, q-1
             int mv_s1 = 0, mv_s2 = 0, mv_s3 = 0;
@@ -571,10 +634,29 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
                 }
                 if (T < 1.) ++u;  // :92-94
             };
-            for (uint32_t q = 0; q < cnt; q += 3) {
-                do_step(q, nb1, lab1);
-                if (q + 1 < cnt) do_step(q + 1, nb2, lab2);
-                if (q + 2 < cnt) do_step(q + 2, nb3, lab3);
+            if (RNG == RNG_COMPAT) {
+                // compat mode: ONE copy of the step in the loop.  Its step is ~1000 instructions long (serial sums,
+                // libstdc++'s distributions), so the labels of step q+1, requested when step q starts, have long
+                // landed when the stage registers are rotated; three unrolled copies of the body (90 KB of code) ran
+                // a lone wave out of the instruction cache.
+#pragma nounroll
+                for (uint32_t q = 0; q < cnt; ++q) {
+                    do_step(q, nb1, lab1);  // consumes stage 1, refills it with step q + 3
+                    const uint32_t nb_t = nb1;
+                    const int lab_t = lab1;
+                    nb1 = nb2;
+                    lab1 = lab2;
+                    nb2 = nb3;
+                    lab2 = lab3;
+                    nb3 = nb_t;
+                    lab3 = lab_t;
+                }
+            } else {
+                for (uint32_t q = 0; q < cnt; q += 3) {
+                    do_step(q, nb1, lab1);
+                    if (q + 1 < cnt) do_step(q + 1, nb2, lab2);
+                    if (q + 2 < cnt) do_step(q + 2, nb3, lab3);
+                }
             }
         }
         ++sweeps_total;
@@ -608,6 +690,10 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
             for (uint32_t i = lane; i < p.n; i += kWave) vg[i] = vl[i];
         }
     }
+#ifdef BISBM_GSTAMPS
+    if (lane == 0)
+        for (int i = 0; i < 10; ++i) atomicAdd(&g_generic_stamps[i], c.st_acc[i]);
+#endif
     if (lane == 0) {
         sc->cum_dS = c.cum_dS;
         sc->accu_r = c.accu_r;
@@ -801,6 +887,19 @@ hipError_t launch_sweep(const SweepParams& p, int rng_mode, size_t lds_bytes, hi
         e = p.eta_in_lds ? launch_sweep_variant<RNG_PHILOX, true>(p, lds_bytes, stream)
                          : launch_sweep_variant<RNG_PHILOX, false>(p, lds_bytes, stream);
     if (e != hipSuccess) return e;
+#ifdef BISBM_GSTAMPS
+    {
+        (void)hipStreamSynchronize(stream);
+        unsigned long long h[16] = {0};
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_generic_stamps), sizeof(h));
+        const double steps = (double)p.n_chains * (double)(p.duration / p.n) * (double)p.n;
+        static const char* names[9] = {"visit-list shuffle", "step entry / bookkeeping", "k_v histogram", "proposal",
+                                       "terms + log_q", "serial sums + tail", "accept", "apply", "chunk header"};
+        for (int i = 0; i < 9; ++i) fprintf(stderr, "[gstamps] %-26s %8.2f ticks/step\n", names[i], (double)h[i] / steps);
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_generic_stamps), z, sizeof(z));
+    }
+#endif
     return hipGetLastError();
 }
 

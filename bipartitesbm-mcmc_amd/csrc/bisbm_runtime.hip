@@ -602,7 +602,7 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
         p.eta_in_lds = (lds + eta_bytes <= 40 * 1024) ? 1 : 0;
         if (p.eta_in_lds) lds += eta_bytes;
         if (h->rng_mode == BISBM_RNG_MT19937_COMPAT) {
-            lds += sizeof(uint32_t) * 624 * 2;
+            lds += sizeof(uint32_t) * 624 * 4;  // two states and their tempered outputs
             if (sizeof(uint32_t) * h->n <= 48 * 1024) {
                 p.vlist_in_lds = 1;
                 lds += sizeof(uint32_t) * h->n;
