@@ -161,6 +161,17 @@ struct CsrCacheHeader {
 };
 static_assert(sizeof(CsrCacheHeader) == 48, "cache header layout");
 constexpr char kCsrMagic[8] = {'B', 'I', 'S', 'B', 'M', 'C', 'S', 'R'};
+
+// rowptr starts at 0 and never decreases, every neighbour id is a node: what the walks below index with
+bool csr_is_sound(uint64_t n, const uint64_t* rowptr, const uint32_t* col) {
+    if (rowptr[0] != 0) return false;
+    for (uint64_t v = 0; v < n; ++v)
+        if (rowptr[v + 1] < rowptr[v]) return false;
+    if (rowptr[n] && !col) return false;
+    for (uint64_t e = 0; e < rowptr[n]; ++e)
+        if (col[e] >= n) return false;
+    return true;
+}
 }  // namespace
 
 int bisbm_io_load_csr(const char* path, uint64_t n, int use_cache, uint64_t** rowptr, uint32_t** col, uint64_t* n_edges,
@@ -183,8 +194,8 @@ int bisbm_io_load_csr(const char* path, uint64_t n, int use_cache, uint64_t** ro
                 uint64_t* rp = (uint64_t*)std::malloc(sizeof(uint64_t) * (n + 1));
                 uint32_t* cl = (uint32_t*)std::malloc(sizeof(uint32_t) * (2 * h.n_edges + 1));
                 ok = rp && cl && std::fread(rp, sizeof(uint64_t), n + 1, f) == n + 1 &&
-                     (h.n_edges == 0 || std::fread(cl, sizeof(uint32_t), 2 * h.n_edges, f) == 2 * h.n_edges) && rp[0] == 0 &&
-                     rp[n] == 2 * h.n_edges;
+                     (h.n_edges == 0 || std::fread(cl, sizeof(uint32_t), 2 * h.n_edges, f) == 2 * h.n_edges) &&
+                     rp[n] == 2 * h.n_edges && csr_is_sound(n, rp, cl);  // a damaged body falls back to the text
                 if (ok) {
                     std::fclose(f);
                     *rowptr = rp;
@@ -321,7 +332,7 @@ struct KdOrder {
 }  // namespace
 
 int bisbm_io_locality_order(uint64_t n, uint64_t na, const uint64_t* rowptr, const uint32_t* col, uint32_t* new_id) {
-    if (!rowptr || !new_id || na > n || n >= 0xffffffffull || (rowptr[n] && !col)) return -1;
+    if (!rowptr || !new_id || na > n || n >= 0xffffffffull || !csr_is_sound(n, rowptr, col)) return -1;
     std::vector<float> x((size_t)n * kEmbedDim), y((size_t)n * kEmbedDim);
     uint64_t state = 0x9E3779B97F4A7C15ull;  // fixed start: splitmix64
     for (size_t i = 0; i < x.size(); ++i) {
@@ -391,10 +402,11 @@ int bisbm_io_locality_order(uint64_t n, uint64_t na, const uint64_t* rowptr, con
 
 int bisbm_io_permute_csr(uint64_t n, const uint64_t* rowptr, const uint32_t* col, const uint32_t* new_id, uint64_t* rowptr_out,
                          uint32_t* col_out) {
-    if (!rowptr || !new_id || !rowptr_out || (rowptr[n] && (!col || !col_out))) return -1;
-    std::vector<uint32_t> old_of(n);
+    if (!rowptr || !new_id || !rowptr_out || n >= 0xffffffffull || !csr_is_sound(n, rowptr, col) || (rowptr[n] && !col_out))
+        return -1;
+    std::vector<uint32_t> old_of(n, 0xffffffffu);
     for (uint64_t v = 0; v < n; ++v) {
-        if (new_id[v] >= n) return -1;
+        if (new_id[v] >= n || old_of[new_id[v]] != 0xffffffffu) return -1;  // not a bijection of [0, n)
         old_of[new_id[v]] = (uint32_t)v;
     }
     rowptr_out[0] = 0;

@@ -20,7 +20,10 @@ _f64p = C.POINTER(C.c_double)
 
 
 def build_oracle():
-    """(Re)build the checker libraries when they are missing (gcc/g++ only; seconds)."""
+    """(Re)build the checker libraries when they are missing (gcc/g++ only; seconds).  BISBM_ORACLE_SO points the binding
+    at another build of the same source (the sanitizer run of tests/test_sanitizers.py)."""
+    if os.environ.get("BISBM_ORACLE_SO"):
+        return os.environ["BISBM_ORACLE_SO"]
     so = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
     chk = os.path.join(ORACLE_DIR, "_build", "libstdcheck.so")
     src = os.path.join(ORACLE_DIR, "bisbm_oracle.c")
