@@ -1,0 +1,64 @@
+"""Long-run consistency check of the production kernel (diagnostic; results in profiles/r02_soak.txt).
+
+After many sweeps of every chain, three things must still hold for EVERY chain, or some update somewhere was applied wrongly
+(a speculative second step kept when it should have been redone, a counter updated twice, a lost label write):
+  * the incrementally maintained block state (m, m_r, n_r, eta) equals a recount from the chain's labels,
+  * the label histogram equals n_r, sum(n_r) = N, sum(m_r) = 2E,
+  * the accumulated sum of accepted dS equals the change of the full description length entropy() (FP tolerance: the sum
+    has ~1e8 terms per chain).
+usage: soak.py WORKLOAD SWEEPS [SCHEDULE K0 K1]      WORKLOAD = bench | n_1000 | config5
+"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+B = importlib.import_module("bipartitesbm-mcmc_amd")
+SYN = importlib.import_module("bipartitesbm-mcmc_amd.synthetic")
+
+workload, sweeps = sys.argv[1], int(sys.argv[2])
+schedule = sys.argv[3] if len(sys.argv) > 3 else "constant"
+kw = [float(x) for x in sys.argv[4:6]] if len(sys.argv) > 4 else [1.0]
+if workload == "bench":
+    na = nb = 500_000; ka = kb = 32; ne = 10_000_000; chains = 1024; eps = 1.0
+    a, b = SYN.planted_edges(na, nb, ne, ka, kb, seed=1)
+    rowptr, col = B.edge_to_adj((a, b), na + nb)
+elif workload == "config5":
+    na = nb = 2_000_000; ka = kb = 64; ne = 50_000_000; chains = 256; eps = 1.0
+    a, b = SYN.planted_edges(na, nb, ne, ka, kb, seed=1)
+    rowptr, col = B.edge_to_adj((a, b), na + nb)
+else:
+    na = nb = 500; ka, kb = 4, 6; chains = 4096; eps = 1.0
+    rowptr, col = B.load_graph(os.path.join("tests", "golden", "bisbm-n_1000-ka_4-kb_6.edgelist"), na + nb)
+    ne = int(rowptr[-1]) // 2
+n = na + nb
+g = B.BlockModel(SYN.contiguous_labels(na, nb, ka, kb), SYN.types_vector(na, nb), ka + kb, ka, kb, eps, (rowptr, col),
+                 n_chains=chains, rng="philox", seed=11)
+g.shuffle_bisbm()
+s0 = g.entropy()
+mh = B.MetropolisHasting()
+t0 = time.time()
+done = 0
+while done < sweeps:  # in slices, so that a progress line appears every minute or so
+    k = min(sweeps - done, max(1, int(50e9 / (chains * n))))
+    rates = mh.anneal(g, schedule, kw, k * n, 1 << 60)
+    done += k
+    print("  %d sweeps, %.0f s, acceptance %.3f" % (done, time.time() - t0, float(np.mean(rates))), flush=True)
+s1 = g.entropy()
+cum = g.get_entropy()
+drift = np.abs((s1 - s0) - cum)
+state = [(g.get_m(c), g.get_m_r(c), g.get_n_r(c), g.get_eta_rk_(c), g.get_memberships(c)) for c in range(chains)]
+g.init_bisbm()  # recount everything from the labels
+bad = 0
+for c, (m, m_r, n_r, eta, lab) in enumerate(state):
+    ok = ((g.get_m(c) == m).all() and (g.get_m_r(c) == m_r).all() and (g.get_n_r(c) == n_r).all() and (g.get_eta_rk_(c) == eta).all()
+          and n_r.sum() == n and m_r.sum() == 2 * ne and (np.bincount(lab, minlength=ka + kb) == n_r).all() and (n_r > 0).all())
+    bad += 0 if ok else 1
+print("%s: %d chains x %d sweeps (%s %s) = %.3e updates: chains with an inconsistent state: %d; |sum dS - (S1 - S0)| max %.3e "
+      "(|sum dS| max %.3e, relative %.1e)" % (workload, chains, sweeps, schedule, kw, chains * sweeps * n, bad, drift.max(),
+                                              np.abs(cum).max(), (drift / np.maximum(np.abs(cum), 1.0)).max()), flush=True)
+sys.exit(1 if bad or (drift / np.maximum(np.abs(cum), 1.0)).max() > 1e-9 else 0)
