@@ -8,6 +8,7 @@
 // (the reference is noexcept-and-terminate).
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <iostream>
@@ -228,6 +229,25 @@ public:
     void summary(uint32_t chain = 0) {                                    // blockmodel.cc:748-751
         std::clog << "(Ka, Kb) = (" << KA_ << ", " << KB_ << ") \n";
         std::clog << "entropy: " << entropy(chain) << "\n";
+    }
+    // Marginal histogram over samples and chains (what README.md:49-53 describes for "marginalization" and the reference's
+    // code never does): reset, add the present labels of every chain, read the MAP label of every node
+    // (most frequent block, ties -> lowest index) in the reference's block numbering.
+    void marginals_reset() { check(bisbm_marginals_reset(h_)); }
+    void marginals_accumulate() { check(bisbm_marginals_accumulate(h_, nullptr)); }
+    uint_vec_t marginal_map_labels(size_t NA) {
+        const size_t kmax = std::max(KA_, KB_);
+        std::vector<uint32_t> counts(n_ * kmax);
+        check(bisbm_marginals_get(h_, counts.data()));
+        uint_vec_t out(n_);
+        for (size_t v = 0; v < n_; ++v) {
+            const uint32_t* row = &counts[v * kmax];
+            size_t best = 0;
+            for (size_t k = 1; k < kmax; ++k)
+                if (row[k] > row[best]) best = k;
+            out[v] = (unsigned)(best + (v >= NA ? KA_ : 0));
+        }
+        return out;
     }
     bisbm_handle handle() const { return h_; }
     uint32_t n_chains() const { return n_chains_; }

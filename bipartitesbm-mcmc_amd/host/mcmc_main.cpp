@@ -4,7 +4,7 @@
 // partition rules (:241-326), same stdout contract: the label vector through output_vec (trailing blank,
 // newline), "acceptance ratio" and summary() on clog (:483-485).  Boost.program_options is replaced by a
 // small parser with the same surface (long/short names, `--opt=value`, multitoken options).
-// Extra flags: --chains, --device, --rng {mt19937-compat,philox}, --gen_seed, --csr_cache, --reorder.
+// Extra flags: --chains, --device, --rng {mt19937-compat,philox}, --gen_seed, --csr_cache, --reorder, --marginalize.
 // The agglomerative drivers (:349-451) run through bisbm_agg_merge; block counts are limited to 256 by the label
 // format, so --merge (one block per node to start with) is for graphs of at most 256 nodes.
 // Negative diffs (agg_split) run through the same call (blockmodel.cc:110-117).
@@ -42,7 +42,7 @@ const option_spec kOptions[] = {
     {"seed", 'd', 1},           {"help", 'h', 0},
     // engine extras
     {"chains", 0, 1},           {"device", 0, 1},          {"rng", 0, 1},          {"gen_seed", 0, 1},
-    {"csr_cache", 0, 0},        {"reorder", 0, 0},
+    {"csr_cache", 0, 0},        {"reorder", 0, 0},         {"marginalize", 0, 0},
 };
 
 const option_spec* find_long(const std::string& name) {
@@ -159,6 +159,10 @@ void print_help(const char* argv0) {
                  "  --reorder                             Renumber the nodes for memory locality before the run (ids without\n"
                  "                                        structure); labels are read and printed in the caller's numbering.\n"
                  "                                        The run is a different, equally valid chain than without the flag.\n"
+                 "  --marginalize                         The marginalization mode of README.md:49-94 (the reference parses -b and\n"
+                 "                                        -f and drops them): T = 1, -b burn-in steps, then -t steps with a\n"
+                 "                                        sample every -f steps (whole sweeps, at least one between samples);\n"
+                 "                                        prints every node's most frequent block over samples and chains.\n"
                  "  --csr_cache                           Keep a binary CSR beside the edge list (<path>.bisbm_csr, checked\n"
                  "                                        against the file's size and mtime); the text file stays the input.\n";
 }
@@ -532,6 +536,47 @@ int main(int argc, char const* argv[]) {
             }
             algorithm.anneal(blockmodel, &abrupt_cool_schedule, kwargs, sampling_steps, steps_await);  // :447
             print_best(blockmodel, false);
+        } catch (const std::exception& e) {
+            std::cerr << e.what() << "\n";
+            return 3;
+        }
+        return 0;
+    }
+
+    if (var_map.count("marginalize")) {
+        // The marginalization mode README.md:49-94 describes and the reference's main never runs (-b and -f are parsed
+        // and dropped, mcmc_main.cc:61-65): constant T = 1; -b burn-in steps; then -t sampling steps with a sample every
+        // -f steps; every sample adds every chain's labels to a per-node histogram; the output line is each node's most
+        // frequent block.  Steps are executed in whole sweeps, as anneal() does (duration / N), with at least one sweep
+        // between samples.
+        try {
+            const size_t N = NA + NB;
+            const size_t burn_in = std::strtoull(single("burn_in", "1000").c_str(), nullptr, 10);
+            const size_t freq = std::strtoull(single("sampling_frequency", "10").c_str(), nullptr, 10);
+            const size_t sweeps_between = std::max<size_t>(1, freq / N);
+            const size_t n_samples = sampling_steps / (sweeps_between * N);
+            blockmodel_t blockmodel(memberships_init, types_init, KA + KB, KA, KB, epsilon, &adj_list, opt);
+            if (randomize)
+                blockmodel.shuffle_bisbm();
+            else
+                blockmodel.init_bisbm();
+            metropolis_hasting algorithm;
+            const float_vec_t t1{1.f, 0.f};
+            const size_t never = std::numeric_limits<size_t>::max();
+            if (burn_in >= N) algorithm.anneal(blockmodel, &constant_schedule, t1, burn_in, never);
+            blockmodel.marginals_reset();
+            for (size_t sample = 0; sample < n_samples; ++sample) {
+                algorithm.anneal(blockmodel, &constant_schedule, t1, sweeps_between * N, never);
+                blockmodel.marginals_accumulate();
+            }
+            std::clog << "marginalize: burn-in " << burn_in / N << " sweeps, " << n_samples << " samples " << sweeps_between
+                      << " sweep(s) apart, " << opt.n_chains << " chain(s) pooled\n";
+            if (n_samples == 0) {
+                std::cerr << "[error] --marginalize: -t " << sampling_steps << " steps hold no sample (" << sweeps_between * N
+                          << " steps per sample)\n";
+                return 1;
+            }
+            emit_labels(blockmodel.marginal_map_labels(NA));
         } catch (const std::exception& e) {
             std::cerr << e.what() << "\n";
             return 3;

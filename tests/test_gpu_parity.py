@@ -805,6 +805,45 @@ def test_cli_reorder_runs_the_renumbered_graph_and_prints_the_callers_numbering(
     assert plain.returncode == 0 and plain.stdout != r.stdout  # (another chain: the visit order is keyed on ids)
 
 
+def test_cli_marginalize_matches_oracle_replay_and_the_python_driver():
+    """`mcmc --marginalize` (the mode README.md:49-94 describes; -b / -f are dead flags in the reference): burn-in, samples
+    every -f steps in whole sweeps, MAP label per node over samples and chains.  One compat chain replayed with the
+    oracle; eight Philox chains against the Python driver on the same seeds."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "bipartitesbm-mcmc_amd", "bin", "mcmc")
+    el = os.path.join(O.GOLDEN, "bisbm-n_1000-ka_4-kb_6.edgelist")
+    sizes = [125] * 4 + [84, 84, 83, 83, 83, 83]
+    common = [cli, "-e", el, "-y", "500", "500", "-n", *map(str, sizes), "-z", "4", "6", "-b", "3000", "-t", "20000", "-f", "2000",
+              "-E", "1", "-d", "3", "--gen_seed", "4", "--marginalize"]
+    burn, between, samples, n = 3, 2, 10, 1000
+    r = subprocess.run(common, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "10 samples 2 sweep(s) apart" in r.stderr
+    rowptr, col = B.load_graph(el, n)
+    o = O.OracleModel(rowptr, col, 500, 500, 4, 6, 1.0, O.labels_from_sizes(sizes))
+    o.seed_compat(3, 4)
+    o.init_bisbm()
+    o.anneal("constant", [1.0], burn * n, BIG)
+    want = np.zeros((n, 6), dtype=np.int64)
+    for _ in range(samples):
+        o.anneal("constant", [1.0], between * n, BIG)
+        want += B.distributed.numpy_marginals(o.memberships()[None, :], 500, 4, 6)
+    base = np.where(np.arange(n) >= 500, 4, 0)
+    assert r.stdout == " ".join(map(str, want.argmax(axis=1) + base)) + " \n"
+    # several Philox chains, randomised start: the Python driver on the same seeds pools the same histogram
+    r8 = subprocess.run(common + ["--rng", "philox", "--chains", "8", "--randomize"], capture_output=True, text=True)
+    assert r8.returncode == 0, r8.stderr
+    g = gpu_model(rowptr, col, 500, 500, 4, 6, 1.0, O.labels_from_sizes(sizes), n_chains=8, rng="philox", seed=3)
+    g.shuffle_bisbm()
+    lab, counts = B.marginalize(g, burn, samples, between)
+    assert counts.sum() == 8 * samples * n
+    assert r8.stdout == " ".join(map(str, lab)) + " \n"
+    # too few steps for one sample: an error, not an empty line
+    bad = subprocess.run(common[:-1] + ["-t", "500", "--marginalize"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "no sample" in bad.stderr
+
+
 # ------------------------------------------------------------------ full size: properties
 def test_full_size_properties():
     """BASELINE configs[2] as benchmarked (N_a=N_b=5e5, E=1e7, Ka=Kb=32, 1024 chains): one sweep keeps the

@@ -59,13 +59,13 @@ def test_cli_argument_handling_under_sanitizers(san_dir):
              good + ["--chains"], good + ["--chains", "0"], good + ["--chains", "-4"], good + ["--chains", "99999999999999999999"],
              good + ["--rng", "nonsense"], good + ["--rng"], good + ["-c", "nonsense"], good + ["-a"], good + ["-t", "abc"],
              good + ["-t", "-1"], good + ["-E", "nan"], good + ["-d", "1e99"], good + ["--merge"], good + ["--merge", "--nature"],
-             good + ["--membership_path", "/nonexistent"], good + ["--csr_cache", "--reorder"], good + ["--unknown-flag", "3"],
+             good + ["--membership_path", "/nonexistent"], good + ["--csr_cache", "--reorder"], good + ["--marginalize"], good + ["--marginalize", "-b", "x", "-f", "0"], good + ["--unknown-flag", "3"],
              ["-y", "1", "1", "-n", "1", "1", "-z", "1", "1", "-e", el],  # ids beyond n
              ["-e", el, "-y", "18", "14", "-n", "30", "2", "-z", "1", "1", "-t", "10"],  # block sizes that do not add up
              ["-e", el, "-y", "0", "0", "-n", "-z", "0", "0"], ["-e", el, "-y", "18", "14", "-z", "300", "5", "-n"] + ["1"] * 305]
     rng = random.Random(7)
     vocab = ["-e", el, "-y", "-n", "-z", "-t", "-x", "-c", "-a", "-E", "-d", "--randomize", "--merge", "--nature", "--chains", "--rng",
-             "philox", "mt19937-compat", "--maximize", "-b", "-f", "--membership_path", "--csr_cache", "--reorder", "0", "1", "5", "18", "14",
+             "philox", "mt19937-compat", "--maximize", "-b", "-f", "--membership_path", "--csr_cache", "--reorder", "--marginalize", "0", "1", "5", "18", "14",
              "-1", "1e9", "", "constant", "linear", "abrupt_cool", "logarithmic", "exponential", "x" * 300]
     for _ in range(60):
         cases.append([rng.choice(vocab) for _ in range(rng.randint(1, 25))])
