@@ -145,7 +145,7 @@ N_CHAINS_PHILOX = 24000
 BURN_IN_PHILOX = 40
 
 
-def _oracle_samples(mode, n_chains, burn_in):
+def _oracle_samples(mode, n_chains, burn_in, T=1.0):
     rowptr, col = cases.enumerable_graph()
     na, nb = cases.ENUM_NA, cases.ENUM_NB
     start = O.contiguous_labels(na, nb, 2, 2)
@@ -158,7 +158,7 @@ def _oracle_samples(mode, n_chains, burn_in):
         else:
             o.seed_philox(4242, c)
         o.shuffle_bisbm()
-        o.anneal("constant", [1.0], burn_in * (na + nb), 1 << 60)
+        o.anneal("constant", [T], burn_in * (na + nb), 1 << 60)
         codes[c] = cases.state_code(o.memberships())
     return codes
 
@@ -190,6 +190,19 @@ def test_chains_sample_exp_minus_S(mode, enum_pi):
     w = np.exp(-(S - S.min()) / 1.15)
     stat2, dof2, p2 = cases.chi_square(codes, states, w / w.sum())
     assert p2 < 1e-6, (stat2, dof2, p2)
+
+
+def test_chains_at_another_temperature_sample_exp_minus_S_over_T(enum_pi):
+    """The same at constant T = 2 in the reference's arithmetic: a = -dS / T + log(accu_r) (metropolis_hasting.cc:52-57)
+    targets exp(-S / T); tests/test_gpu_scale.py runs T = 2 and T = 0.6 on the production kernel."""
+    states, _, S = enum_pi
+    codes = _oracle_samples("compat", 24000, 40, T=2.0)
+    target = np.exp(-(S - S.min()) / 2.0)
+    stat, dof, p = cases.chi_square(codes, states, target / target.sum())
+    print("compat, T = 2: chi2 = %.1f on %d dof, p = %.3g" % (stat, dof, p))
+    assert p > 1e-3, (stat, dof, p)
+    w = np.exp(-(S - S.min()) / 2.5)  # power: T = 2.5 is rejected by the same samples
+    assert cases.chi_square(codes, states, w / w.sum())[2] < 1e-6
 
 
 # ------------------------------------------------------------------ the rule behind "two steps per pass" (DESIGN.md section 6)

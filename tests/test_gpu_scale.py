@@ -31,31 +31,34 @@ def assert_state_equal(g, o, chain=0):
 
 
 # ------------------------------------------------------------------ stationary distribution of the production chain
-def test_gpu_chains_sample_exp_minus_S():
-    """32768 independent Philox chains of the production kernel on the 6+6-node graph, one sample each after a burn-in
-    from a randomised start, against exp(-S) over the 3844 admissible states (S = entropy(), blockmodel.cc:753-787)
-    -- the same test tests/test_cross_mode.py runs on the oracle in the reference's arithmetic."""
+@pytest.mark.parametrize("T", [1.0, 2.0, 0.6])
+def test_gpu_chains_sample_exp_minus_S(T):
+    """32768 independent Philox chains of the production kernel on the 6+6-node graph at constant temperature T, one sample
+    each after a burn-in from a randomised start, against exp(-S / T) over the 3844 admissible states (S = entropy(),
+    blockmodel.cc:753-787; the acceptance rule a = -dS / T + log(accu_r), metropolis_hasting.cc:52-57, has that stationary
+    distribution) -- the same test tests/test_cross_mode.py runs on the oracle in the reference's arithmetic."""
     rowptr, col = cases.enumerable_graph()
     na, nb = cases.ENUM_NA, cases.ENUM_NB
     start = O.contiguous_labels(na, nb, 2, 2)
-    chains, burn_in = 32768, 30
+    chains, burn_in = 32768, 100
     g = gpu_model(rowptr, col, na, nb, 2, 2, cases.ENUM_EPS, start, n_chains=chains, rng="philox", seed=4242)
     g.shuffle_bisbm()
-    B.MetropolisHasting().anneal(g, "constant", [1.0], burn_in * (na + nb), BIG)
+    B.MetropolisHasting().anneal(g, "constant", [T], burn_in * (na + nb), BIG)
     labs = [g.get_memberships(c) for c in range(chains)]
     codes = np.array([cases.state_code(l) for l in labs])
-    states, prob, S = cases.enumerable_states()
-    stat, dof, p = cases.chi_square(codes, states, prob)
-    print("GPU philox: chi2 = %.1f on %d dof, p = %.3g" % (stat, dof, p))
+    states, _, S = cases.enumerable_states()
+    target = np.exp(-(S - S.min()) / T)
+    stat, dof, p = cases.chi_square(codes, states, target / target.sum())
+    print("GPU philox, T = %g: chi2 = %.1f on %d dof, p = %.3g" % (T, stat, dof, p))
     assert p > 1e-3, (stat, dof, p)
-    w = np.exp(-(S - S.min()) / 1.15)  # power: a slightly wrong target is rejected by the same samples
+    w = np.exp(-(S - S.min()) / (1.25 * T))  # power: a somewhat wrong target is rejected by the same samples
     assert cases.chi_square(codes, states, w / w.sum())[2] < 1e-6
     # and the chains are the oracle's chains
     for c in (0, 1, 777, chains - 1):
         o = O.OracleModel(rowptr, col, na, nb, 2, 2, cases.ENUM_EPS, start)
         o.seed_philox(4242, c)
         o.shuffle_bisbm()
-        o.anneal("constant", [1.0], burn_in * (na + nb), BIG)
+        o.anneal("constant", [T], burn_in * (na + nb), BIG)
         assert (o.memberships() == labs[c]).all()
 
 
