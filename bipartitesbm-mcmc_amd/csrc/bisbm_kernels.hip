@@ -25,6 +25,7 @@
 #include "bisbm_kernels.hpp"
 
 #include <cstdio>
+#include <type_traits>
 
 namespace bisbm {
 
@@ -60,6 +61,8 @@ struct ChainCtx {
     bool eta_lds;
     // global
     uint8_t* labels;
+    uint16_t* labels16;  // wide mode (K > 256): two-byte labels, and ...
+    int32_t* mg;         // ... the a x b quadrant of m stays in HBM (row stride kb): it no longer fits the LDS
     // shape
     uint32_t ka, kb, K, S, D;  // S = LDS row stride of mq, D = maxdeg + 1
     uint32_t na;
@@ -91,8 +94,28 @@ __device__ __forceinline__ void eta_store(const ChainCtx& c, uint32_t idx, uint3
 }
 
 // m[own block i][opposite block j] for a node of the given type, from the a x b quadrant
+template <bool W>
 __device__ __forceinline__ int32_t& Mx(const ChainCtx& c, bool type_b, uint32_t i_own, uint32_t j_oth) {
-    return type_b ? c.mq[j_oth * c.S + i_own] : c.mq[i_own * c.S + j_oth];
+    if constexpr (W)
+        return type_b ? c.mg[j_oth * c.kb + i_own] : c.mg[i_own * c.kb + j_oth];
+    else
+        return type_b ? c.mq[j_oth * c.S + i_own] : c.mq[i_own * c.S + j_oth];
+}
+
+// label of a node: a byte, or two in wide mode
+template <bool W>
+__device__ __forceinline__ uint32_t lab_at(const ChainCtx& c, uint32_t v) {
+    if constexpr (W)
+        return c.labels16[v];
+    else
+        return c.labels[v];
+}
+template <bool W>
+__device__ __forceinline__ void lab_set(const ChainCtx& c, uint32_t v, uint32_t s) {
+    if constexpr (W)
+        c.labels16[v] = (uint16_t)s;
+    else
+        c.labels[v] = (uint8_t)s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -110,7 +133,7 @@ __device__ __forceinline__ void wave_fence() {
     __asm__ volatile("" ::: "memory");
 }
 
-template <int RNG, bool EL>
+template <int RNG, bool EL, bool W>
 __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab, ChainCtx& c, Mt& engine, Mt& gen,
                                         uint32_t v, uint32_t beg, uint32_t deg, uint32_t r, uint32_t nb_reg,
                                         int lab_reg, double T, uint64_t gstep, uint32_t chain_gid, uint32_t* s_out) {
@@ -129,7 +152,7 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
     wave_fence();
     if ((uint32_t)lane < deg) atomicAdd(&c.hist[lab_reg - (int)oth_base], 1);
     for (uint32_t j = kWave + lane; j < deg; j += kWave)  // rows longer than one wave (rare)
-        atomicAdd(&c.hist[(int)c.labels[p.col[beg + j]] - (int)oth_base], 1);
+        atomicAdd(&c.hist[(int)lab_at<W>(c, p.col[beg + j]) - (int)oth_base], 1);
     wave_fence();
     GSTAMP(c, 2);
 
@@ -163,7 +186,7 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
             uint32_t which = (uint32_t)(u_idx * (double)deg);
             if (which >= deg) which = deg - 1;
             const uint32_t t = which < (uint32_t)kWave ? (uint32_t)readlane(lab_reg, which)
-                                                        : (uint32_t)c.labels[p.col[beg + which]];
+                                                        : lab_at<W>(c, p.col[beg + which]);
             const int32_t mrt = c.mr[t];
             if (u_R * (mrt + c.epsilon * (double)K) < c.epsilon * (double)K) {  // :622-624 without the division
                 s = (uint32_t)(u_tgt * (double)K);
@@ -177,7 +200,7 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
                 s = own_base + k_own - 1;
                 for (uint32_t c0 = 0; c0 < k_own; c0 += kWave) {
                     const uint32_t i = c0 + lane;
-                    const int w = i < k_own ? Mx(c, type_b, i, t_loc) : 0;
+                    const int w = i < k_own ? Mx<W>(c, type_b, i, t_loc) : 0;
                     const int scan = wave_inclusive_scan(w);
                     const long long cum = carry + (long long)scan;
                     const unsigned long long hit = __ballot(i < k_own && cum > x);
@@ -201,7 +224,7 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
         } else {
             const uint32_t which = (uint32_t)(draw_engine() * (double)deg);
             const uint32_t t = which < (uint32_t)kWave ? (uint32_t)readlane(lab_reg, which)
-                                                        : (uint32_t)c.labels[p.col[beg + which]];
+                                                        : lab_at<W>(c, p.col[beg + which]);
             const int32_t mrt = c.mr[t];
             const double R_t = c.epsilon * (double)K / (mrt + c.epsilon * (double)K);
             if (draw_engine() < R_t) {
@@ -218,7 +241,7 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
                 for (uint32_t c0 = 0; c0 < K && !found; c0 += kWave) {
                     const uint32_t g = c0 + lane;
                     int32_t w = 0;
-                    if (g < K && g >= own_base && g < own_base + k_own) w = Mx(c, type_b, g - own_base, t_loc);
+                    if (g < K && g >= own_base && g < own_base + k_own) w = Mx<W>(c, type_b, g - own_base, t_loc);
                     const double pr = (double)w / sum;
                     // partial sums in index order; a zero weight adds +0.0 (the sum keeps its bits), so only the
                     // non-zero entries take a serial step and every lane keeps the sum up to its own index
@@ -287,8 +310,8 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
             Terms t{0, 0, 0, 0, 0., 0., 0., 0.};
             if (j < k_oth) t.k = c.hist[j];
             if (t.k != 0) {
-                t.m_rt = Mx(c, type_b, r_loc, j);
-                t.m_st = Mx(c, type_b, s_loc, j);
+                t.m_rt = Mx<W>(c, type_b, r_loc, j);
+                t.m_st = Mx<W>(c, type_b, s_loc, j);
                 t.mr_t = c.mr[oth_base + j];
                 t.L1 = lgamma_fast(tab, (long long)t.m_rt + 1);
                 t.L2 = lgamma_fast(tab, (long long)t.m_st + 1);
@@ -410,15 +433,15 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
         }
         atomicSub(&c.mr[r], (int)deg);
         atomicAdd(&c.mr[s], (int)deg);
-        c.labels[v] = (uint8_t)s;
+        lab_set<W>(c, v, s);
     }
     {
         const uint32_t s_loc = s - own_base;
         for (uint32_t j = lane; j < k_oth; j += kWave) {  // :479-487 (mirror entries are the same cells here)
             const int k = c.hist[j];
             if (k != 0) {
-                atomicSub(&Mx(c, type_b, r_loc, j), k);
-                atomicAdd(&Mx(c, type_b, s_loc, j), k);
+                atomicSub(&Mx<W>(c, type_b, r_loc, j), k);
+                atomicAdd(&Mx<W>(c, type_b, s_loc, j), k);
             }
         }
     }
@@ -437,7 +460,7 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
 //   * the neighbour ids of step q+2 and the neighbour labels of step q+1 are in flight while step q
 //     computes (labels fetched early are patched when step q moves one of those neighbours).
 // ------------------------------------------------------------------------------------------
-template <int RNG, bool EL>
+template <int RNG, bool EL, bool W>
 __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const uint32_t chain = blockIdx.x;
@@ -452,7 +475,7 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
     ChainCtx c;
     unsigned char* cur = lds_raw;
     c.mq = (int32_t*)cur;
-    cur += sizeof(int32_t) * p.ka * S;
+    if (!W) cur += sizeof(int32_t) * p.ka * S;
     c.mr = (int32_t*)cur;
     cur += sizeof(int32_t) * K;
     c.nr = (int32_t*)cur;
@@ -485,6 +508,7 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
         }
     }
     c.labels = p.labels + (size_t)chain * p.label_stride;
+    c.labels16 = (uint16_t*)p.labels + (size_t)chain * p.label_stride;
     c.ka = p.ka;
     c.kb = p.kb;
     c.K = K;
@@ -497,7 +521,9 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
     int32_t* m_g = p.m + (size_t)chain * p.ka * p.kb;
     int32_t* mr_g = p.m_r + (size_t)chain * K;
     int32_t* nr_g = p.n_r + (size_t)chain * K;
-    for (uint32_t i = lane; i < p.ka * p.kb; i += kWave) c.mq[(i / p.kb) * S + (i % p.kb)] = m_g[i];
+    c.mg = m_g;
+    if (!W)
+        for (uint32_t i = lane; i < p.ka * p.kb; i += kWave) c.mq[(i / p.kb) * S + (i % p.kb)] = m_g[i];
     for (uint32_t i = lane; i < K; i += kWave) {
         c.mr[i] = mr_g[i];
         c.nr[i] = nr_g[i];
@@ -562,7 +588,7 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
                 v_l = (RNG == RNG_COMPAT) ? vl[pos] : (pos < p.na ? order_a(pos) : p.na + order_b(pos - p.na));
                 beg_l = p.rowptr[v_l];
                 deg_l = p.rowptr[v_l + 1] - beg_l;
-                r_l = c.labels[v_l];
+                r_l = lab_at<W>(c, v_l);
             }
             // CSR staging: the chunk's 64 adjacency rows (first 64 ids of each) go HBM -> LDS by
             // LDS-DMA, one 256-B row slot per instruction, all of them in flight together
@@ -585,7 +611,7 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
                     const uint32_t id = ids_lds[qq * kWave + lane];
                     const bool on = (uint32_t)lane < d;
                     nb = on ? id : 0xFFFFFFFFu;
-                    lab = c.labels[on ? id : 0u];
+                    lab = (int)lab_at<W>(c, on ? id : 0u);
                 }
             };
             // three stage registers in fixed roles (the loop is unrolled by the depth): a register that is
@@ -614,7 +640,7 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
                 const double T = temperature_of(p, current_step + vi);  // :84
                 uint32_t s = r;
                 prefetch();
-                const bool ok = mh_step<RNG, EL>(p, tab, c, engine, gen, v, beg, deg, r, nbC, labC, T,
+                const bool ok = mh_step<RNG, EL, W>(p, tab, c, engine, gen, v, beg, deg, r, nbC, labC, T,
                                                  sweeps_total * num_nodes + vi, chain_gid, &s);
                 mv_v1 = mv_v2;
                 mv_s1 = mv_s2;
@@ -671,7 +697,8 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
 
     // store the chain back
     __syncthreads();
-    for (uint32_t i = lane; i < p.ka * p.kb; i += kWave) m_g[i] = c.mq[(i / p.kb) * S + (i % p.kb)];
+    if (!W)
+        for (uint32_t i = lane; i < p.ka * p.kb; i += kWave) m_g[i] = c.mq[(i / p.kb) * S + (i % p.kb)];
     for (uint32_t i = lane; i < K; i += kWave) {
         mr_g[i] = c.mr[i];
         nr_g[i] = c.nr[i];
@@ -706,10 +733,12 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
     }
 }
 
-template __global__ void sweep_kernel<RNG_PHILOX, true>(SweepParams);
-template __global__ void sweep_kernel<RNG_PHILOX, false>(SweepParams);
-template __global__ void sweep_kernel<RNG_COMPAT, true>(SweepParams);
-template __global__ void sweep_kernel<RNG_COMPAT, false>(SweepParams);
+template __global__ void sweep_kernel<RNG_PHILOX, true, false>(SweepParams);
+template __global__ void sweep_kernel<RNG_PHILOX, false, false>(SweepParams);
+template __global__ void sweep_kernel<RNG_COMPAT, true, false>(SweepParams);
+template __global__ void sweep_kernel<RNG_COMPAT, false, false>(SweepParams);
+template __global__ void sweep_kernel<RNG_PHILOX, false, true>(SweepParams);  // wide mode: eta stays in HBM as well
+template __global__ void sweep_kernel<RNG_COMPAT, false, true>(SweepParams);
 
 // ------------------------------------------------------------------------------------------
 // state build: init_bisbm (blockmodel.cc:682-688, compute_n_r :740-746, compute_m :702-714,
@@ -717,13 +746,15 @@ template __global__ void sweep_kernel<RNG_COMPAT, false>(SweepParams);
 // a x b quadrant is histogrammed in LDS from the type-a rows of the CSR (the b rows are its
 // transpose), eta / n_r with global atomics on the chain's own (zeroed) arrays.
 // ------------------------------------------------------------------------------------------
+template <bool W>
 __global__ __launch_bounds__(256) void state_build_kernel(BuildParams p) {
+    using LabelT = std::conditional_t<W, uint16_t, uint8_t>;
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    int32_t* mq = (int32_t*)lds_raw;  // ka*kb
     const uint32_t chain = blockIdx.x;
     const uint32_t K = p.ka + p.kb, D = p.maxdeg + 1;
-    const uint8_t* labels = p.labels + (size_t)chain * p.label_stride;
+    const LabelT* labels = (const LabelT*)p.labels + (size_t)chain * p.label_stride;
     int32_t* m_g = p.m + (size_t)chain * p.ka * p.kb;
+    int32_t* mq = W ? m_g : (int32_t*)lds_raw;  // ka*kb: in LDS, or (wide mode) counted straight into the chain's array
     int32_t* mr_g = p.m_r + (size_t)chain * K;
     int32_t* nr_g = p.n_r + (size_t)chain * K;
     uint32_t* eta_g = p.eta + (size_t)chain * K * D;
@@ -749,7 +780,7 @@ __global__ __launch_bounds__(256) void state_build_kernel(BuildParams p) {
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < p.ka * p.kb; i += blockDim.x) {
         const int32_t x = mq[i];
-        m_g[i] = x;
+        if (!W) m_g[i] = x;
         if (x) {
             atomicAdd(&mr_g[i / p.kb], x);
             atomicAdd(&mr_g[p.ka + i % p.kb], x);
@@ -758,26 +789,36 @@ __global__ __launch_bounds__(256) void state_build_kernel(BuildParams p) {
 }
 
 // set_memberships: u32 host labels (staged on device) -> u8, one chain or broadcast to all
-__global__ void labels_broadcast_kernel(const uint32_t* src, uint8_t* labels, size_t label_stride,
+template <class LabelT>
+__global__ void labels_broadcast_kernel(const uint32_t* src, LabelT* labels, size_t label_stride,
                                         uint32_t n, uint32_t first_chain, uint32_t n_chains) {
     const uint32_t chain = first_chain + blockIdx.y;
     if (blockIdx.y >= n_chains) return;
-    uint8_t* dst = labels + (size_t)chain * label_stride;
+    LabelT* dst = labels + (size_t)chain * label_stride;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        dst[i] = (uint8_t)src[i];
+        dst[i] = (LabelT)src[i];
 }
 
-__global__ void labels_widen_kernel(const uint8_t* labels, uint32_t* dst, uint32_t n) {
+template <class LabelT>
+__global__ void labels_widen_kernel(const LabelT* labels, uint32_t* dst, uint32_t n) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         dst[i] = labels[i];
 }
 
+// wide -> narrow once merges have brought K down to 256 blocks or fewer: every chain's two-byte labels into a byte array
+__global__ void labels_narrow_kernel(const uint16_t* src, uint8_t* dst, size_t label_stride, uint32_t n) {
+    const uint16_t* s = src + (size_t)blockIdx.y * label_stride;
+    uint8_t* d = dst + (size_t)blockIdx.y * label_stride;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = (uint8_t)s[i];
+}
+
 // shuffle_bisbm, Philox definition: each type's labels are gathered through a keyed Feistel
 // permutation (block sizes preserved).  grid = (tiles, chains).
+template <class LabelT>
 __global__ void shuffle_philox_kernel(ShuffleParams p) {
     const uint32_t chain = blockIdx.y;
-    const uint8_t* src = p.labels_old + (size_t)chain * p.label_stride;
-    uint8_t* dst = p.labels + (size_t)chain * p.label_stride;
+    const LabelT* src = (const LabelT*)p.labels_old + (size_t)chain * p.label_stride;
+    LabelT* dst = (LabelT*)p.labels + (size_t)chain * p.label_stride;
     const uint32_t gid = p.first_chain_id + chain;
     const uint32_t epoch = p.scalars[chain].shuffle_epoch;
     Feistel fa, fb;
@@ -793,6 +834,7 @@ __global__ void shuffle_epoch_bump_kernel(ChainScalars* sc, uint32_t n_chains) {
 }
 
 // shuffle_bisbm, compat: two std::shuffle calls on `engine` (blockmodel.cc:673-674)
+template <class LabelT>
 __global__ __launch_bounds__(kWave) void shuffle_compat_kernel(ShuffleParams p) {
     __shared__ uint32_t mt_lds[624];
     const uint32_t chain = blockIdx.x;
@@ -801,7 +843,7 @@ __global__ __launch_bounds__(kWave) void shuffle_compat_kernel(ShuffleParams p) 
     for (uint32_t i = lane; i < 624; i += kWave) mt_lds[i] = eg[i];
     __syncthreads();
     Mt engine{mt_lds, (int)p.scalars[chain].engine_idx};
-    uint8_t* labels = p.labels + (size_t)chain * p.label_stride;
+    LabelT* labels = (LabelT*)p.labels + (size_t)chain * p.label_stride;
     mt_shuffle(engine, labels, p.na);
     mt_shuffle(engine, labels + p.na, p.nb);
     __syncthreads();
@@ -869,18 +911,21 @@ __global__ void log_q_probe_kernel(Tables tab, const int32_t* n, const int32_t* 
 // ------------------------------------------------------------------------------------------
 // launchers (called from the host runtime)
 // ------------------------------------------------------------------------------------------
-template <int RNG, bool EL>
+template <int RNG, bool EL, bool W = false>
 static hipError_t launch_sweep_variant(const SweepParams& p, size_t lds_bytes, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)sweep_kernel<RNG, EL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)sweep_kernel<RNG, EL, W>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((sweep_kernel<RNG, EL>), dim3(p.n_chains), dim3(kWave), lds_bytes, stream, p);
+    hipLaunchKernelGGL((sweep_kernel<RNG, EL, W>), dim3(p.n_chains), dim3(kWave), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
 hipError_t launch_sweep(const SweepParams& p, int rng_mode, size_t lds_bytes, hipStream_t stream) {
     hipError_t e;
-    if (rng_mode == RNG_COMPAT)
+    if (p.wide)  // K > 256: two-byte labels, m and eta in HBM
+        e = rng_mode == RNG_COMPAT ? launch_sweep_variant<RNG_COMPAT, false, true>(p, lds_bytes, stream)
+                                   : launch_sweep_variant<RNG_PHILOX, false, true>(p, lds_bytes, stream);
+    else if (rng_mode == RNG_COMPAT)
         e = p.eta_in_lds ? launch_sweep_variant<RNG_COMPAT, true>(p, lds_bytes, stream)
                          : launch_sweep_variant<RNG_COMPAT, false>(p, lds_bytes, stream);
     else
@@ -904,62 +949,108 @@ hipError_t launch_sweep(const SweepParams& p, int rng_mode, size_t lds_bytes, hi
 }
 
 hipError_t launch_state_build(const BuildParams& p, hipStream_t stream) {
+    if (p.wide) {
+        hipLaunchKernelGGL(state_build_kernel<true>, dim3(p.n_chains), dim3(256), 0, stream, p);
+        return hipGetLastError();
+    }
     const size_t lds = sizeof(int32_t) * p.ka * p.kb;
-    hipError_t e = hipFuncSetAttribute((const void*)state_build_kernel,
+    hipError_t e = hipFuncSetAttribute((const void*)state_build_kernel<false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(state_build_kernel, dim3(p.n_chains), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(state_build_kernel<false>, dim3(p.n_chains), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
-hipError_t launch_labels_broadcast(const uint32_t* src, uint8_t* labels, size_t label_stride, uint32_t n,
+hipError_t launch_labels_broadcast(const uint32_t* src, uint8_t* labels, bool wide, size_t label_stride, uint32_t n,
                                    uint32_t first_chain, uint32_t n_chains, hipStream_t stream) {
     const uint32_t tiles = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
-    hipLaunchKernelGGL(labels_broadcast_kernel, dim3(tiles ? tiles : 1, n_chains), dim3(256), 0, stream, src,
-                       labels, label_stride, n, first_chain, n_chains);
+    if (wide)
+        hipLaunchKernelGGL(labels_broadcast_kernel<uint16_t>, dim3(tiles ? tiles : 1, n_chains), dim3(256), 0, stream, src,
+                           (uint16_t*)labels, label_stride, n, first_chain, n_chains);
+    else
+        hipLaunchKernelGGL(labels_broadcast_kernel<uint8_t>, dim3(tiles ? tiles : 1, n_chains), dim3(256), 0, stream, src,
+                           labels, label_stride, n, first_chain, n_chains);
+    return hipGetLastError();
+}
+
+hipError_t launch_labels_narrow(const uint8_t* wide_labels, uint8_t* labels, size_t label_stride, uint32_t n, uint32_t n_chains,
+                                hipStream_t stream) {
+    const uint32_t tiles = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
+    hipLaunchKernelGGL(labels_narrow_kernel, dim3(tiles ? tiles : 1, n_chains), dim3(256), 0, stream, (const uint16_t*)wide_labels,
+                       labels, label_stride, n);
     return hipGetLastError();
 }
 
 // ---- relabelling after block merges (apply_block_moves, blockmodel.cc:567-611) ----
 // first[chain][l] = lowest node id whose label maps to l under map1 (the order in which the reference compacts)
-__global__ void merge_first_kernel(const uint8_t* labels, size_t label_stride, uint32_t n, const uint8_t* map1,
+// Maps are [chain][map_len] tables of LabelT (map_len = the block count before the call, rounded up to 256), `first` is
+// [chain][map_len].  The tables are staged in dynamic LDS (map_len entries each).
+template <class LabelT>
+__global__ void merge_first_kernel(const LabelT* labels, size_t label_stride, uint32_t n, uint32_t map_len, const LabelT* map1,
                                    uint32_t* first) {
-    __shared__ uint32_t lfirst[256];
-    __shared__ uint8_t lmap[256];
+    extern __shared__ __align__(16) unsigned char merge_lds[];
+    uint32_t* lfirst = (uint32_t*)merge_lds;
+    LabelT* lmap = (LabelT*)(lfirst + map_len);
     const uint32_t chain = blockIdx.y;
-    lfirst[threadIdx.x] = 0xffffffffu;
-    lmap[threadIdx.x] = map1[(size_t)chain * 256 + threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < map_len; i += blockDim.x) {
+        lfirst[i] = 0xffffffffu;
+        lmap[i] = map1[(size_t)chain * map_len + i];
+    }
     __syncthreads();
-    const uint8_t* lab = labels + (size_t)chain * label_stride;
+    const LabelT* lab = labels + (size_t)chain * label_stride;
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x)
         atomicMin(&lfirst[lmap[lab[v]]], v);
     __syncthreads();
-    if (lfirst[threadIdx.x] != 0xffffffffu) atomicMin(&first[(size_t)chain * 256 + threadIdx.x], lfirst[threadIdx.x]);
+    for (uint32_t i = threadIdx.x; i < map_len; i += blockDim.x)
+        if (lfirst[i] != 0xffffffffu) atomicMin(&first[(size_t)chain * map_len + i], lfirst[i]);
 }
 
-__global__ void merge_relabel_kernel(uint8_t* labels, size_t label_stride, uint32_t n, const uint8_t* fmap) {
-    __shared__ uint8_t lmap[256];
+template <class LabelT>
+__global__ void merge_relabel_kernel(LabelT* labels, size_t label_stride, uint32_t n, uint32_t map_len, const LabelT* fmap) {
+    extern __shared__ __align__(16) unsigned char merge_lds[];
+    LabelT* lmap = (LabelT*)merge_lds;
     const uint32_t chain = blockIdx.y;
-    lmap[threadIdx.x] = fmap[(size_t)chain * 256 + threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < map_len; i += blockDim.x) lmap[i] = fmap[(size_t)chain * map_len + i];
     __syncthreads();
-    uint8_t* lab = labels + (size_t)chain * label_stride;
+    LabelT* lab = labels + (size_t)chain * label_stride;
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) lab[v] = lmap[lab[v]];
 }
 
-hipError_t launch_merge_first(const uint8_t* labels, size_t label_stride, uint32_t n, uint32_t n_chains,
-                              const uint8_t* map1, uint32_t* first, hipStream_t stream) {
+template <class LabelT>
+static hipError_t launch_merge_first_t(const LabelT* labels, size_t label_stride, uint32_t n, uint32_t n_chains, uint32_t map_len,
+                                       const LabelT* map1, uint32_t* first, hipStream_t stream) {
     const uint32_t tiles = std::min<uint32_t>((n + 256 * 16 - 1) / (256 * 16), 1024u);
-    hipLaunchKernelGGL(merge_first_kernel, dim3(tiles ? tiles : 1, n_chains), dim3(256), 0, stream, labels, label_stride, n,
-                       map1, first);
+    const size_t lds = (sizeof(uint32_t) + sizeof(LabelT)) * map_len;
+    hipError_t e = hipFuncSetAttribute((const void*)merge_first_kernel<LabelT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(merge_first_kernel<LabelT>, dim3(tiles ? tiles : 1, n_chains), dim3(256), lds, stream, labels, label_stride, n,
+                       map_len, map1, first);
     return hipGetLastError();
 }
 
-hipError_t launch_merge_relabel(uint8_t* labels, size_t label_stride, uint32_t n, uint32_t n_chains, const uint8_t* fmap,
-                                hipStream_t stream) {
+hipError_t launch_merge_first(const uint8_t* labels, bool wide, size_t label_stride, uint32_t n, uint32_t n_chains, uint32_t map_len,
+                              const void* map1, uint32_t* first, hipStream_t stream) {
+    return wide ? launch_merge_first_t<uint16_t>((const uint16_t*)labels, label_stride, n, n_chains, map_len, (const uint16_t*)map1,
+                                                 first, stream)
+                : launch_merge_first_t<uint8_t>(labels, label_stride, n, n_chains, map_len, (const uint8_t*)map1, first, stream);
+}
+
+template <class LabelT>
+static hipError_t launch_merge_relabel_t(LabelT* labels, size_t label_stride, uint32_t n, uint32_t n_chains, uint32_t map_len,
+                                         const LabelT* fmap, hipStream_t stream) {
     const uint32_t tiles = std::min<uint32_t>((n + 256 * 16 - 1) / (256 * 16), 1024u);
-    hipLaunchKernelGGL(merge_relabel_kernel, dim3(tiles ? tiles : 1, n_chains), dim3(256), 0, stream, labels, label_stride, n,
-                       fmap);
+    const size_t lds = sizeof(LabelT) * map_len;
+    hipError_t e = hipFuncSetAttribute((const void*)merge_relabel_kernel<LabelT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(merge_relabel_kernel<LabelT>, dim3(tiles ? tiles : 1, n_chains), dim3(256), lds, stream, labels, label_stride, n,
+                       map_len, fmap);
     return hipGetLastError();
+}
+
+hipError_t launch_merge_relabel(uint8_t* labels, bool wide, size_t label_stride, uint32_t n, uint32_t n_chains, uint32_t map_len,
+                                const void* fmap, hipStream_t stream) {
+    return wide ? launch_merge_relabel_t<uint16_t>((uint16_t*)labels, label_stride, n, n_chains, map_len, (const uint16_t*)fmap, stream)
+                : launch_merge_relabel_t<uint8_t>(labels, label_stride, n, n_chains, map_len, (const uint8_t*)fmap, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1130,18 +1221,28 @@ hipError_t launch_split_apply(const SplitParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_labels_widen(const uint8_t* labels, uint32_t* dst, uint32_t n, hipStream_t stream) {
+// one chain's labels (`labels` points at the chain's first label) -> u32
+hipError_t launch_labels_widen(const uint8_t* labels, bool wide, uint32_t* dst, uint32_t n, hipStream_t stream) {
     const uint32_t tiles = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
-    hipLaunchKernelGGL(labels_widen_kernel, dim3(tiles ? tiles : 1), dim3(256), 0, stream, labels, dst, n);
+    if (wide)
+        hipLaunchKernelGGL(labels_widen_kernel<uint16_t>, dim3(tiles ? tiles : 1), dim3(256), 0, stream, (const uint16_t*)labels, dst, n);
+    else
+        hipLaunchKernelGGL(labels_widen_kernel<uint8_t>, dim3(tiles ? tiles : 1), dim3(256), 0, stream, labels, dst, n);
     return hipGetLastError();
 }
 
 hipError_t launch_shuffle(const ShuffleParams& p, int rng_mode, hipStream_t stream) {
     if (rng_mode == RNG_COMPAT) {
-        hipLaunchKernelGGL(shuffle_compat_kernel, dim3(p.n_chains), dim3(kWave), 0, stream, p);
+        if (p.wide)
+            hipLaunchKernelGGL(shuffle_compat_kernel<uint16_t>, dim3(p.n_chains), dim3(kWave), 0, stream, p);
+        else
+            hipLaunchKernelGGL(shuffle_compat_kernel<uint8_t>, dim3(p.n_chains), dim3(kWave), 0, stream, p);
     } else {
         const uint32_t tiles = (p.n + 255) / 256 < 1024 ? (p.n + 255) / 256 : 1024;
-        hipLaunchKernelGGL(shuffle_philox_kernel, dim3(tiles ? tiles : 1, p.n_chains), dim3(256), 0, stream, p);
+        if (p.wide)
+            hipLaunchKernelGGL(shuffle_philox_kernel<uint16_t>, dim3(tiles ? tiles : 1, p.n_chains), dim3(256), 0, stream, p);
+        else
+            hipLaunchKernelGGL(shuffle_philox_kernel<uint8_t>, dim3(tiles ? tiles : 1, p.n_chains), dim3(256), 0, stream, p);
         hipLaunchKernelGGL(shuffle_epoch_bump_kernel, dim3((p.n_chains + 255) / 256), dim3(256), 0, stream,
                            p.scalars, p.n_chains);
     }

@@ -68,6 +68,9 @@ struct SweepParams {
     uint32_t fixed_stepping_wave;
     // production kernel, K <= 32 and constant T: evaluate two consecutive steps per pass (0: one step per pass)
     uint32_t pair_steps;
+    // wide mode (KA + KB > 256; generic kernel only): `labels` holds two-byte labels (label_stride counts labels, not
+    // bytes), and the a x b quadrant of m is read and updated in HBM
+    uint32_t wide;
 };
 constexpr uint32_t kSimdClaims = 1u << 14;  // index: XCC_ID[3:0] | HW_ID se, sh, cu [15:8] | simd [5:4]
 
@@ -81,6 +84,7 @@ struct BuildParams {
     int32_t* m_r;
     int32_t* n_r;
     uint32_t* eta;
+    uint32_t wide;  // two-byte labels, m counted in HBM (see SweepParams::wide)
 };
 
 struct ShuffleParams {
@@ -91,6 +95,7 @@ struct ShuffleParams {
     size_t label_stride;
     ChainScalars* scalars;
     uint32_t* mt_engine;
+    uint32_t wide;
 };
 
 struct EntropyParams {
@@ -166,14 +171,18 @@ hipError_t launch_sweep(const SweepParams& p, int rng_mode, size_t lds_bytes, hi
 hipError_t launch_sweep_fast(const SweepParams& p, size_t lds_bytes, hipStream_t stream);
 size_t sweep_fast_lds_bytes(uint32_t ka, uint32_t kb, uint32_t maxdeg, bool eta_in_lds);
 hipError_t launch_state_build(const BuildParams& p, hipStream_t stream);
-hipError_t launch_labels_broadcast(const uint32_t* src, uint8_t* labels, size_t label_stride, uint32_t n,
+// `labels` is the byte base of the label array; wide: two-byte labels (label_stride counts labels in both cases)
+hipError_t launch_labels_broadcast(const uint32_t* src, uint8_t* labels, bool wide, size_t label_stride, uint32_t n,
                                    uint32_t first_chain, uint32_t n_chains, hipStream_t stream);
-hipError_t launch_labels_widen(const uint8_t* labels, uint32_t* dst, uint32_t n, hipStream_t stream);
-// relabelling after block merges: map1 / fmap are [n_chains][256] byte tables, first is [n_chains][256] (preset to ~0)
-hipError_t launch_merge_first(const uint8_t* labels, size_t label_stride, uint32_t n, uint32_t n_chains,
-                              const uint8_t* map1, uint32_t* first, hipStream_t stream);
-hipError_t launch_merge_relabel(uint8_t* labels, size_t label_stride, uint32_t n, uint32_t n_chains, const uint8_t* fmap,
+hipError_t launch_labels_widen(const uint8_t* labels, bool wide, uint32_t* dst, uint32_t n, hipStream_t stream);
+hipError_t launch_labels_narrow(const uint8_t* wide_labels, uint8_t* labels, size_t label_stride, uint32_t n, uint32_t n_chains,
                                 hipStream_t stream);
+// relabelling after block merges: map1 / fmap are [n_chains][map_len] tables of labels (bytes, or two bytes when wide), first is
+// [n_chains][map_len] (preset to ~0); map_len = the block count before the call rounded up to a multiple of 256
+hipError_t launch_merge_first(const uint8_t* labels, bool wide, size_t label_stride, uint32_t n, uint32_t n_chains, uint32_t map_len,
+                              const void* map1, uint32_t* first, hipStream_t stream);
+hipError_t launch_merge_relabel(uint8_t* labels, bool wide, size_t label_stride, uint32_t n, uint32_t n_chains, uint32_t map_len,
+                                const void* fmap, hipStream_t stream);
 hipError_t launch_shuffle(const ShuffleParams& p, int rng_mode, hipStream_t stream);
 hipError_t launch_entropy(const EntropyParams& p, hipStream_t stream);
 hipError_t launch_marginals(const MarginalParams& p, hipStream_t stream);

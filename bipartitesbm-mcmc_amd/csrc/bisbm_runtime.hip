@@ -186,9 +186,12 @@ struct bisbm_engine {
     // device memory
     uint32_t* d_rowptr = nullptr;
     uint32_t* d_col = nullptr;
-    uint8_t* d_labels = nullptr;
+    uint8_t* d_labels = nullptr;      // [chain][label_stride] labels: bytes, or two bytes each while `wide`
     uint8_t* d_labels_tmp = nullptr;
-    size_t label_stride = 0;
+    size_t label_stride = 0;          // in labels
+    bool wide = false;                // KA + KB > 256 (a --merge run starts at one block per node): generic kernel only,
+                                      // two-byte labels, m read and updated in HBM; back to bytes once K <= 256
+    size_t lbytes() const { return wide ? 2 : 1; }
     uint32_t* d_vlist = nullptr;
     int32_t* d_m = nullptr;
     int32_t* d_m_r = nullptr;
@@ -275,6 +278,7 @@ int rebuild_state(bisbm_engine* h) {
     bp.n_chains = h->n_chains;
     bp.labels = h->d_labels;
     bp.label_stride = h->label_stride;
+    bp.wide = h->wide ? 1u : 0u;
     bp.m = h->d_m;
     bp.m_r = h->d_m_r;
     bp.n_r = h->d_n_r;
@@ -301,7 +305,8 @@ int bisbm_create(bisbm_handle* out, uint64_t n, uint64_t na, uint64_t nb, const 
     if (!rowptr || (!col && rowptr[n] != 0)) return fail(nullptr, BISBM_ERR_INVALID_ARG, "rowptr/col is NULL");
     if (n == 0 || na + nb != n) return fail(nullptr, BISBM_ERR_INVALID_ARG, "na + nb must equal n > 0");
     if (ka == 0 || kb == 0) return fail(nullptr, BISBM_ERR_INVALID_ARG, "ka and kb must be >= 1");
-    if (ka + kb > 256) return fail(nullptr, BISBM_ERR_UNSUPPORTED, "ka + kb = %u > 256 (labels are stored as uint8)", ka + kb);
+    if ((uint64_t)ka + kb > 65535) return fail(nullptr, BISBM_ERR_UNSUPPORTED, "ka + kb = %llu > 65535 (labels are at most two bytes)", (unsigned long long)ka + kb);
+    if (ka > na || kb > nb) return fail(nullptr, BISBM_ERR_INVALID_ARG, "more blocks than nodes of a type (ka %u / na %llu, kb %u / nb %llu)", ka, (unsigned long long)na, kb, (unsigned long long)nb);
     if (n_chains == 0) return fail(nullptr, BISBM_ERR_INVALID_ARG, "n_chains must be >= 1");
     if (rng_mode != BISBM_RNG_PHILOX && rng_mode != BISBM_RNG_MT19937_COMPAT)
         return fail(nullptr, BISBM_ERR_INVALID_ARG, "unknown rng_mode %d", rng_mode);
@@ -348,6 +353,7 @@ int bisbm_create(bisbm_handle* out, uint64_t n, uint64_t na, uint64_t nb, const 
     h->label_stride = (n + 255) & ~(uint64_t)255;
     h->cap_ka = ka;
     h->cap_kb = kb;
+    h->wide = ka + kb > 256;
 
     auto bail = [&](int code) {
         g_create_error = h->err;
@@ -383,7 +389,7 @@ int bisbm_create(bisbm_handle* out, uint64_t n, uint64_t na, uint64_t nb, const 
     CCHK(dalloc(&h->d_rowptr, n + 1));
     CCHK(dalloc(&h->d_col, nnz + 4));  // four spare entries: the production kernel reads a row's ids 16 bytes at a time
     CCHK(hipMemset(h->d_col, 0, sizeof(uint32_t) * (nnz + 4)));
-    CCHK(dalloc(&h->d_labels, C * h->label_stride));
+    CCHK(dalloc(&h->d_labels, C * h->label_stride * h->lbytes()));
     CCHK(dalloc(&h->d_m, C * ka * kb));
     CCHK(dalloc(&h->d_m_r, C * K));
     CCHK(dalloc(&h->d_n_r, C * K));
@@ -399,7 +405,7 @@ int bisbm_create(bisbm_handle* out, uint64_t n, uint64_t na, uint64_t nb, const 
         CCHK(dalloc(&h->d_mt_engine, C * 624));
         CCHK(dalloc(&h->d_mt_gen, C * 624));
     } else {
-        CCHK(dalloc(&h->d_labels_tmp, C * h->label_stride));
+        CCHK(dalloc(&h->d_labels_tmp, C * h->label_stride * h->lbytes()));
     }
 
     {
@@ -410,7 +416,7 @@ int bisbm_create(bisbm_handle* out, uint64_t n, uint64_t na, uint64_t nb, const 
         CCHK(hipMemcpy(h->d_lgamma, h->tab->lg.data(), sizeof(double) * h->tab->lg.size(), hipMemcpyHostToDevice));
         CCHK(hipMemcpy(h->d_logtab, h->tab->lo.data(), sizeof(double) * h->tab->lo.size(), hipMemcpyHostToDevice));
         CCHK(hipMemcpy(h->d_q, h->tab->q.data(), sizeof(double) * h->tab->q.size(), hipMemcpyHostToDevice));
-        CCHK(hipMemset(h->d_labels, 0, C * h->label_stride));
+        CCHK(hipMemset(h->d_labels, 0, C * h->label_stride * h->lbytes()));
         std::vector<ChainScalars> sc(C);
         for (auto& s : sc) {
             std::memset(&s, 0, sizeof(s));
@@ -483,7 +489,7 @@ int bisbm_set_memberships(bisbm_handle h, int64_t chain, const uint32_t* labels)
     HIPCHK(h, hipMemcpyAsync(h->d_stage_u32, labels, sizeof(uint32_t) * h->n, hipMemcpyHostToDevice, h->stream));
     const uint32_t first = chain == BISBM_ALL_CHAINS ? 0 : (uint32_t)chain;
     const uint32_t cnt = chain == BISBM_ALL_CHAINS ? h->n_chains : 1;
-    HIPCHK(h, launch_labels_broadcast(h->d_stage_u32, h->d_labels, h->label_stride, (uint32_t)h->n, first, cnt, h->stream));
+    HIPCHK(h, launch_labels_broadcast(h->d_stage_u32, h->d_labels, h->wide, h->label_stride, (uint32_t)h->n, first, cnt, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->state_ready = false;
     return BISBM_OK;
@@ -510,8 +516,9 @@ int bisbm_shuffle(bisbm_handle h) {
     sp.label_stride = h->label_stride;
     sp.scalars = h->d_scalars;
     sp.mt_engine = h->d_mt_engine;
+    sp.wide = h->wide ? 1u : 0u;
     if (h->rng_mode == BISBM_RNG_PHILOX)
-        HIPCHK(h, hipMemcpyAsync(h->d_labels_tmp, h->d_labels, (size_t)h->n_chains * h->label_stride,
+        HIPCHK(h, hipMemcpyAsync(h->d_labels_tmp, h->d_labels, (size_t)h->n_chains * h->label_stride * h->lbytes(),
                                  hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, launch_shuffle(sp, h->rng_mode, h->stream));
     return rebuild_state(h);
@@ -540,6 +547,7 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     p.first_chain_id = h->first_chain_id;
     p.labels = h->d_labels;
     p.label_stride = h->label_stride;
+    p.wide = h->wide ? 1u : 0u;
     p.vlist = h->d_vlist;
     p.m = h->d_m;
     p.m_r = h->d_m_r;
@@ -585,7 +593,7 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     // the production kernel covers Philox mode with both block counts <= 64; mt19937-compat mode and
     // wider partitions run the generic kernel (BISBM_FORCE_GENERIC=1 forces it, for A/B checks)
     const char* force = getenv("BISBM_FORCE_GENERIC");
-    const bool fast = h->rng_mode == BISBM_RNG_PHILOX && h->ka <= 64 && h->kb <= 64 && !(force && force[0] == '1');
+    const bool fast = h->rng_mode == BISBM_RNG_PHILOX && h->ka <= 64 && h->kb <= 64 && !h->wide && !(force && force[0] == '1');
     // LDS plan.  eta goes to LDS when that still leaves room for four chains per CU (160 KiB / 4).
     const size_t K = h->K, D = (size_t)h->maxdeg + 1, S = h->kb | 1u;
     const size_t eta_bytes = sizeof(uint32_t) * K * D;
@@ -598,8 +606,8 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     } else {
         // generic kernel: m quadrant (odd row stride), m_r, n_r, k_v histogram, staged rows; compat adds the
         // two mt19937 states and (small graphs) the visit list
-        lds = sizeof(int32_t) * (h->ka * S + 2 * K + std::max<uint32_t>(std::max(h->ka, h->kb), 64)) + sizeof(uint32_t) * 64 * 64;
-        p.eta_in_lds = (lds + eta_bytes <= 40 * 1024) ? 1 : 0;
+        lds = sizeof(int32_t) * ((h->wide ? 0 : h->ka * S) + 2 * K + std::max<uint32_t>(std::max(h->ka, h->kb), 64)) + sizeof(uint32_t) * 64 * 64;
+        p.eta_in_lds = (!h->wide && lds + eta_bytes <= 40 * 1024) ? 1 : 0;
         if (p.eta_in_lds) lds += eta_bytes;
         if (h->rng_mode == BISBM_RNG_MT19937_COMPAT) {
             lds += sizeof(uint32_t) * 624 * 4;  // two states and their tempered outputs
@@ -674,7 +682,7 @@ int bisbm_get_memberships(bisbm_handle h, uint32_t chain, uint32_t* labels_out) 
     if (!h) return BISBM_ERR_INVALID_ARG;
     if (!labels_out || chain >= h->n_chains) return fail(h, BISBM_ERR_INVALID_ARG, "bad chain or NULL output");
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, launch_labels_widen(h->d_labels + (size_t)chain * h->label_stride, h->d_stage_u32, (uint32_t)h->n, h->stream));
+    HIPCHK(h, launch_labels_widen(h->d_labels + (size_t)chain * h->label_stride * h->lbytes(), h->wide, h->d_stage_u32, (uint32_t)h->n, h->stream));
     HIPCHK(h, hipMemcpyAsync(labels_out, h->d_stage_u32, sizeof(uint32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return BISBM_OK;
@@ -788,6 +796,7 @@ int bisbm_marginals_reset(bisbm_handle h) {
 
 int bisbm_marginals_accumulate(bisbm_handle h, uint32_t* device_counts) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    if (h->wide) return fail(h, BISBM_ERR_UNSUPPORTED, "marginal histograms are kept for at most 256 blocks (KA + KB = %u)", h->K);
     HIPCHK(h, hipSetDevice(h->device));
     if (!device_counts) {
         // (a histogram made before a merge / split changed max(KA, KB) has another row length: start afresh)
@@ -909,7 +918,7 @@ struct MergeChain {
     std::vector<int> M;            // K x K, symmetric
     std::vector<int> m_r;          // row sums
     std::vector<uint32_t> first;   // lowest node id of each block
-    std::vector<uint8_t> cmap;     // original label -> current label (256 entries, 0xff = gone)
+    std::vector<uint16_t> cmap;    // original label -> current label (one entry per original block, 0xffff = gone)
     // randomness
     bool compat = false;
     std::mt19937 engine, gen;
@@ -1055,7 +1064,7 @@ struct MergeChain {
                 if (n2o[to[j]] != (size_t)-1) nM[n2o[to[i]] * nK + n2o[to[j]]] += at(i, j);
         }
         for (auto& c : cmap)
-            if (c != 0xff) c = n2o[to[c]] == (size_t)-1 ? 0xff : (uint8_t)n2o[to[c]];
+            if (c != 0xffff) c = n2o[to[c]] == (size_t)-1 ? 0xffff : (uint16_t)n2o[to[c]];
         std::vector<uint32_t> f2(nK);
         for (size_t i = 0; i < nK; ++i) f2[i] = nfirst[order[i]];
         first.swap(f2);
@@ -1148,7 +1157,7 @@ struct MergeChain {
 int run_split(bisbm_engine* h, int type, int nm) {
     if (!h->state_ready) return fail(h, BISBM_ERR_STATE, "call bisbm_init or bisbm_shuffle before bisbm_agg_merge");
     if (nm < 1 || nm > 65535) return fail(h, BISBM_ERR_INVALID_ARG, "nm must be in [1, 65535]");
-    if (h->K + 1 > 256) return fail(h, BISBM_ERR_UNSUPPORTED, "a split would give %u blocks (> 256: labels are stored as uint8)", h->K + 1);
+    if (h->K + 1 > 256) return fail(h, BISBM_ERR_UNSUPPORTED, "a split would give %u blocks (splits are built for at most 256 blocks)", h->K + 1);
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const size_t C = h->n_chains, K = h->K, ka = h->ka, kb = h->kb;
@@ -1383,12 +1392,20 @@ int run_merges(bisbm_engine* h, int which, int diff_a, int diff_b, int nm) {
     const size_t C = h->n_chains, K0 = h->K, ka0 = h->ka, kb0 = h->kb;
 
     // first node of every label, all chains
+    // (label maps hold one entry per block before the call, padded to a multiple of 256; bytes, or two bytes when wide)
+    const size_t L = (K0 + 255) & ~(size_t)255, lb = h->lbytes();
     uint8_t* d_map = nullptr;
     uint32_t* d_first = nullptr;
-    HIPCHK(h, dalloc(&d_map, C * 256));
-    HIPCHK(h, dalloc(&d_first, C * 256));
-    std::vector<uint8_t> ident(C * 256);
-    for (size_t i = 0; i < ident.size(); ++i) ident[i] = (uint8_t)(i & 255);
+    HIPCHK(h, dalloc(&d_map, C * L * lb));
+    HIPCHK(h, dalloc(&d_first, C * L));
+    std::vector<uint8_t> ident(C * L * lb);
+    for (size_t i = 0; i < C * L; ++i) {
+        const uint16_t l = (uint16_t)(i % L);
+        if (h->wide)
+            std::memcpy(&ident[2 * i], &l, 2);
+        else
+            ident[i] = (uint8_t)l;
+    }
     auto cleanup = [&]() {
         (void)hipFree(d_map);
         (void)hipFree(d_first);
@@ -1402,10 +1419,10 @@ int run_merges(bisbm_engine* h, int which, int diff_a, int diff_b, int nm) {
         }                                                                                              \
     } while (0)
     MCHK(hipMemcpy(d_map, ident.data(), ident.size(), hipMemcpyHostToDevice));
-    MCHK(hipMemset(d_first, 0xff, sizeof(uint32_t) * C * 256));
-    MCHK(launch_merge_first(h->d_labels, h->label_stride, (uint32_t)h->n, h->n_chains, d_map, d_first, h->stream));
+    MCHK(hipMemset(d_first, 0xff, sizeof(uint32_t) * C * L));
+    MCHK(launch_merge_first(h->d_labels, h->wide, h->label_stride, (uint32_t)h->n, h->n_chains, (uint32_t)L, d_map, d_first, h->stream));
     MCHK(hipStreamSynchronize(h->stream));
-    std::vector<uint32_t> first(C * 256);
+    std::vector<uint32_t> first(C * L);
     MCHK(hipMemcpy(first.data(), d_first, sizeof(uint32_t) * first.size(), hipMemcpyDeviceToHost));
     std::vector<int32_t> quad(C * ka0 * kb0);
     MCHK(hipMemcpy(quad.data(), h->d_m, sizeof(int32_t) * quad.size(), hipMemcpyDeviceToHost));
@@ -1432,7 +1449,7 @@ int run_merges(bisbm_engine* h, int which, int diff_a, int diff_b, int nm) {
         ss >> pos;
     };
 
-    std::vector<uint8_t> fmap(C * 256, 0);
+    std::vector<uint16_t> fmap(C * L, 0);
     // the chains are independent: K-scale selection per chain, spread over the host's threads
     std::vector<int> rcs(C, 0);
     std::vector<std::pair<size_t, size_t>> ends(C);
@@ -1449,9 +1466,9 @@ int run_merges(bisbm_engine* h, int which, int diff_a, int diff_b, int nm) {
         mc.m_r.assign(K0, 0);
         for (size_t i = 0; i < K0; ++i)
             for (size_t j = 0; j < K0; ++j) mc.m_r[i] += mc.M[i * K0 + j];
-        mc.first.assign(first.begin() + c * 256, first.begin() + c * 256 + K0);
-        mc.cmap.assign(256, 0xff);
-        for (size_t i = 0; i < K0; ++i) mc.cmap[i] = (uint8_t)i;
+        mc.first.assign(first.begin() + c * L, first.begin() + c * L + K0);
+        mc.cmap.assign(L, 0xffff);
+        for (size_t i = 0; i < K0; ++i) mc.cmap[i] = (uint16_t)i;
         mc.compat = compat;
         mc.seed = h->seed;
         mc.chain_gid = h->first_chain_id + (uint32_t)c;
@@ -1466,7 +1483,7 @@ int run_merges(bisbm_engine* h, int which, int diff_a, int diff_b, int nm) {
         rcs[c] = which == 0 ? mc.agg_merge(diff_a, diff_b, nm) : mc.agg_merge_total(diff_a, nm);
         if (rcs[c] != 0) return;
         ends[c] = {mc.ka, mc.kb};
-        for (size_t i = 0; i < 256; ++i) fmap[c * 256 + i] = mc.cmap[i] == 0xff ? 0 : mc.cmap[i];
+        for (size_t i = 0; i < L; ++i) fmap[c * L + i] = mc.cmap[i] == 0xffff ? 0 : mc.cmap[i];
         sc[c].merge_epoch = mc.epoch;
         if (compat) {
             store_mt(mc.engine, &mt_e[c * 624], sc[c].engine_idx);
@@ -1502,8 +1519,13 @@ int run_merges(bisbm_engine* h, int which, int diff_a, int diff_b, int nm) {
                         "chains ended with different block counts (chain 0: %zu+%zu, chain %zu: %zu+%zu); one (Ka,Kb) per handle",
                         nka, nkb, c, ends[c].first, ends[c].second);
         }
-    MCHK(hipMemcpy(d_map, fmap.data(), fmap.size(), hipMemcpyHostToDevice));
-    MCHK(launch_merge_relabel(h->d_labels, h->label_stride, (uint32_t)h->n, h->n_chains, d_map, h->stream));
+    if (h->wide) {
+        MCHK(hipMemcpy(d_map, fmap.data(), sizeof(uint16_t) * fmap.size(), hipMemcpyHostToDevice));
+    } else {
+        std::vector<uint8_t> fmap8(fmap.begin(), fmap.end());
+        MCHK(hipMemcpy(d_map, fmap8.data(), fmap8.size(), hipMemcpyHostToDevice));
+    }
+    MCHK(launch_merge_relabel(h->d_labels, h->wide, h->label_stride, (uint32_t)h->n, h->n_chains, (uint32_t)L, d_map, h->stream));
     MCHK(hipMemcpy(h->d_scalars, sc.data(), sizeof(ChainScalars) * C, hipMemcpyHostToDevice));
     if (compat) {
         MCHK(hipMemcpy(h->d_mt_engine, mt_e.data(), sizeof(uint32_t) * mt_e.size(), hipMemcpyHostToDevice));
@@ -1515,6 +1537,20 @@ int run_merges(bisbm_engine* h, int which, int diff_a, int diff_b, int nm) {
     h->ka = (uint32_t)nka;
     h->kb = (uint32_t)nkb;
     h->K = h->ka + h->kb;
+    if (h->wide && h->K <= 256) {
+        // the merges have brought the partition into the byte-label range: from here on the ordinary kernels run
+        uint8_t* narrow = nullptr;
+        HIPCHK(h, dalloc(&narrow, C * h->label_stride));
+        hipError_t e = launch_labels_narrow(h->d_labels, narrow, h->label_stride, (uint32_t)h->n, h->n_chains, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(narrow);
+            return fail(h, BISBM_ERR_HIP, "labels_narrow: %s", hipGetErrorString(e));
+        }
+        (void)hipFree(h->d_labels);
+        h->d_labels = narrow;
+        h->wide = false;  // (d_labels_tmp, Philox mode, keeps its two-byte size: large enough for either format)
+    }
     return rebuild_state(h);  // init_bisbm() at the end of apply_block_moves (:610)
 }
 

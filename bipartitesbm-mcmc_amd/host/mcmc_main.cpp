@@ -5,8 +5,8 @@
 // newline), "acceptance ratio" and summary() on clog (:483-485).  Boost.program_options is replaced by a
 // small parser with the same surface (long/short names, `--opt=value`, multitoken options).
 // Extra flags: --chains, --device, --rng {mt19937-compat,philox}, --gen_seed, --csr_cache, --reorder, --marginalize.
-// The agglomerative drivers (:349-451) run through bisbm_agg_merge; block counts are limited to 256 by the label
-// format, so --merge (one block per node to start with) is for graphs of at most 256 nodes.
+// The agglomerative drivers (:349-451) run through bisbm_agg_merge.  --merge starts at one block per node: while
+// KA + KB > 256 the library runs its wide mode (two-byte labels, generic kernel), up to 65535 blocks.
 // Negative diffs (agg_split) run through the same call (blockmodel.cc:110-117).
 #include <chrono>
 #include <limits>
@@ -440,10 +440,10 @@ int main(int argc, char const* argv[]) {
         return true;
     };
     if (merge) {
-        if (NA + NB > 256) {  // the start is one block per node (:350-353); block labels are bytes on the device
-            std::cerr << "[error] --merge starts from one block per node (" << NA + NB << " blocks); this engine holds at most 256 "
-                         "blocks. Start from an initial partition of at most 256 blocks (-n / --mb / --membership_path with a "
-                         "larger -z than wanted is merged down the same way, mcmc_main.cc:419-450).\n";
+        if (NA + NB > 65535) {  // the start is one block per node (:350-353); block labels are at most two bytes on the device
+            std::cerr << "[error] --merge starts from one block per node (" << NA + NB << " blocks); this engine holds at most 65535 "
+                         "blocks. Start from an initial partition of fewer blocks (-n / --mb / --membership_path with a larger -z "
+                         "than wanted is merged down the same way, mcmc_main.cc:419-450).\n";
             return 3;
         }
         try {

@@ -29,7 +29,7 @@ typedef enum bisbm_status {
     BISBM_OK = 0,
     BISBM_ERR_INVALID_ARG = 1,   /* null pointer, size mismatch, label out of range ... */
     BISBM_ERR_NOT_BIPARTITE = 2, /* an edge joins two nodes of one type, or an id >= n */
-    BISBM_ERR_UNSUPPORTED = 3,   /* K > 256 (labels are bytes), more than 2^32-1 adjacency entries ... */
+    BISBM_ERR_UNSUPPORTED = 3,   /* K > 65535 (labels are at most two bytes), more than 2^32-1 adjacency entries ... */
     BISBM_ERR_NO_DEVICE = 4,     /* no HIP device / bad ordinal: the engine has no CPU path */
     BISBM_ERR_HIP = 5,           /* a HIP runtime call failed */
     BISBM_ERR_STATE = 6          /* call order (e.g. anneal before init/shuffle) */
@@ -65,7 +65,12 @@ typedef enum bisbm_schedule {
  * [ka,ka+kb) type b.  `n_chains` independent chains are created on HIP device `device`; chain i
  * of this handle has global id first_chain_id + i (the id keys its random stream, so results do
  * not depend on how chains are sharded over GPUs).  Builds the lgamma / log_q tables
- * (support/cache.cc:64-91, support/int_part.cc:34-51) on the host and uploads them. */
+ * (support/cache.cc:64-91, support/int_part.cc:34-51) on the host and uploads them.
+ * ka + kb <= 65535 and no more blocks than nodes of a type.  With ka + kb > 256 (the reference's --merge driver starts from one
+ * block per node, mcmc_main.cc:350-353) the handle runs in WIDE MODE: two-byte labels, the block matrix read and updated in
+ * HBM, the generic kernel (slow per step; meant for the greedy sweeps between merge stages); bisbm_agg_merge switches it to
+ * byte labels and the ordinary kernels as soon as it leaves ka + kb <= 256.  Marginal histograms and splits are refused
+ * (BISBM_ERR_UNSUPPORTED) while wide. */
 int bisbm_create(bisbm_handle *out, uint64_t n, uint64_t na, uint64_t nb, const uint64_t *rowptr,
                  const uint32_t *col, uint32_t ka, uint32_t kb, double epsilon, uint32_t n_chains,
                  uint32_t first_chain_id, int device, int rng_mode, uint64_t seed,

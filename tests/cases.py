@@ -28,6 +28,8 @@ CASES = [
     ("hubs_isolated", 300, 200, 3000, 5, 7, 1.0, 3, 4),
     ("huge_hub", 300, 200, 3000, 5, 7, 1.0, 1, 0),    # degree > 255: beyond the byte counters of the feeder's walk
     ("wideK", 400, 300, 6000, 70, 3, 2.0, 0, 0),       # K_type > 64: chunked lane loops
+    # KA + KB > 256: the library's wide mode (two-byte labels, m read and updated in HBM) -- where a --merge run starts
+    ("wide_labels", 400, 300, 6000, 200, 150, 1.0, 2, 0),
     ("big_m_r", 150, 150, 60000, 2, 3, 1.0, 0, 0),     # m_r > 10^4: log_q_approx on the device
     # production kernel's hot step: m_r > 10^4 and k / sqrt(n) > 24 (closed-form log_q tier), K <= 32 ...
     ("direct_tier", 20000, 20000, 100000, 2, 2, 1.0, 0, 0),

@@ -652,7 +652,12 @@ def test_error_paths():
         gpu_model(rowptr, col, na + 1, nb - 1, 5, 5, 1.0, labels)  # node 18 becomes type a: a-a edges
     assert e.value.code == B.BISBM_ERR_NOT_BIPARTITE
     with pytest.raises(B.BisbmError) as e:
-        gpu_model(rowptr, col, na, nb, 200, 100, 1.0, labels)
+        gpu_model(rowptr, col, na, nb, 200, 100, 1.0, labels)  # more blocks than nodes
+    assert e.value.code == B.BISBM_ERR_INVALID_ARG
+    with pytest.raises(B.BisbmError) as e:  # more than 65535 blocks: labels are at most two bytes
+        big_n = 70000
+        gpu_model(np.zeros(big_n + 1, dtype=np.uint64), np.zeros(0, dtype=np.uint32), 40000, 30000, 40000, 30000, 1.0,
+                  np.arange(big_n, dtype=np.uint32))
     assert e.value.code == B.BISBM_ERR_UNSUPPORTED
     bad = labels.copy()
     bad[0] = 7  # a type-b block for a type-a node
@@ -721,6 +726,74 @@ def test_cli_merge_matches_oracle_replay():
     o.anneal("abrupt_cool", [320.0], 3200, 100000)
     assert r.stdout == " ".join(map(str, o.memberships())) + " \n"
     assert "(Ka, Kb) = (5, 5) " in r.stderr
+
+
+def test_cli_merge_from_singletons_on_1000_nodes():
+    """`mcmc --merge` on the n_1000 data set: the run starts at one block per node (KA + KB = 1000: the library's wide
+    mode, two-byte labels and m in HBM), 463 merge stages with greedy sweeps in between bring it to 4 + 6 (byte labels and
+    the ordinary kernels from 256 blocks down), then the final anneal -- against the same driver replayed with the oracle."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "bipartitesbm-mcmc_amd", "bin", "mcmc")
+    el = os.path.join(O.GOLDEN, "bisbm-n_1000-ka_4-kb_6.edgelist")
+    r = subprocess.run([cli, "-e", el, "-y", "500", "500", "-n", "500", "500", "-z", "4", "6", "--merge", "-t", "10000", "-x", "100000",
+                        "-c", "abrupt_cool", "-a", "100", "-E", "1", "-d", "42", "--gen_seed", "43"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rowptr, col = B.load_graph(el, 1000)
+    na = nb = 500
+    n = na + nb
+    o = O.OracleModel(rowptr, col, na, nb, na, nb, 1.0, np.arange(n, dtype=np.uint32))
+    o.seed_compat(42, 43)
+    o.init_bisbm()
+    ka_s, kb_s = O.geospace(na, 4, nb, 6, 1.01)
+    for i in range(len(ka_s) - 1):
+        assert o.agg_merge(ka_s[i] - ka_s[i + 1], kb_s[i] - kb_s[i + 1], 10) == 0
+        if i != len(ka_s) - 2:
+            o.anneal("abrupt_cool", [0.0], n, 100000)
+    o.anneal("abrupt_cool", [100.0], 10000, 100000)
+    assert r.stdout == " ".join(map(str, o.memberships())) + " \n"
+    assert "(Ka, Kb) = (4, 6) " in r.stderr
+
+
+def test_wide_mode_merges_down_into_byte_labels():
+    """API level, both RNG modes, several chains: 150 + 150 blocks (wide) merged to 140 + 140 (still wide), swept, merged to
+    100 + 100 (byte labels from here), swept -- state equal to the oracle's after every call; what wide mode does not
+    serve (marginal histograms, splits) is refused with a message."""
+    rowptr, col = cases.random_graph(91, 300, 300, 5000, 150, 150)
+    na = nb = 300
+    n = na + nb
+    labels = O.contiguous_labels(na, nb, 150, 150)
+    mh = B.MetropolisHasting()
+    for mode in ("compat", "philox"):
+        chains = 3
+        g = gpu_model(rowptr, col, na, nb, 150, 150, 1.0, labels, n_chains=chains, rng=mode, seed=5, gen_seed=6)
+        g.shuffle_bisbm()
+        os_ = []
+        for c in range(chains):
+            o = O.OracleModel(rowptr, col, na, nb, 150, 150, 1.0, labels)
+            if mode == "compat":
+                o.seed_compat(5 + c, 6 + c)
+            else:
+                o.seed_philox(5, c)
+            o.shuffle_bisbm()
+            os_.append(o)
+        with pytest.raises(RuntimeError, match="256 blocks"):
+            g.marginals_accumulate(None)
+        with pytest.raises(RuntimeError, match="256 blocks"):
+            g.agg_merge(-1, 0, 5)
+        for (da, db), sched in (((10, 10), ("constant", [1.0])), ((40, 40), ("abrupt_cool", [0.0]))):
+            g.agg_merge(da, db, 10)
+            for o in os_:
+                assert o.agg_merge(da, db, 10) == 0
+            rg = mh.anneal(g, sched[0], sched[1], 2 * n, BIG)
+            for c, o in enumerate(os_):
+                ro = o.anneal(sched[0], sched[1], 2 * n, BIG)
+                assert rg[c] == ro
+                assert_state_equal(g, o, c)
+        assert (g.KA, g.KB) == (100, 100)
+        ent = g.entropy()
+        for c, o in enumerate(os_):
+            assert abs(ent[c] - o.entropy()) <= 1e-9 * abs(o.entropy())
 
 
 def test_cli_resume_round_trip(tmp_path):
