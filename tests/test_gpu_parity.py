@@ -755,6 +755,34 @@ def test_cli_merge_from_singletons_on_1000_nodes():
     assert "(Ka, Kb) = (4, 6) " in r.stderr
 
 
+def test_cli_merge_nature_on_1000_nodes():
+    """`mcmc --merge --nature` on n_1000 (mcmc_main.cc:354-377): one-argument agg_merge stages from 1000 blocks (wide mode)
+    down to fewer than sqrt(2E)/2 of a type, greedy sweeps in between -- against the oracle's replay."""
+    import math
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "bipartitesbm-mcmc_amd", "bin", "mcmc")
+    el = os.path.join(O.GOLDEN, "bisbm-n_1000-ka_4-kb_6.edgelist")
+    r = subprocess.run([cli, "-e", el, "-y", "500", "500", "-n", "500", "500", "-z", "1", "1", "--merge", "--nature", "-t", "2000",
+                        "-x", "100000", "-c", "abrupt_cool", "-a", "100", "-E", "1", "-d", "11", "--gen_seed", "12"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rowptr, col = B.load_graph(el, 1000)
+    na = nb = 500
+    n = na + nb
+    o = O.OracleModel(rowptr, col, na, nb, na, nb, 1.0, np.arange(n, dtype=np.uint32))
+    o.seed_compat(11, 12)
+    o.init_bisbm()
+    ceiling = math.ceil(math.sqrt(2.0 * o.num_edges) / 2)
+    tka, tkb = na, nb
+    while tka >= ceiling and tkb >= ceiling:
+        assert o.agg_merge_total(math.ceil((tka + tkb) * (1.01 - 1) / 1.01), 10) == 0
+        tka, tkb = o.ka, o.kb
+        o.anneal("abrupt_cool", [0.0], n, 100000)
+    o.anneal("abrupt_cool", [100.0], 2000, 100000)
+    assert r.stdout == "%d %d " % (o.ka, o.kb) + " ".join(map(str, o.memberships())) + " \n"
+
+
 def test_wide_mode_merges_down_into_byte_labels():
     """API level, both RNG modes, several chains: 150 + 150 blocks (wide) merged to 140 + 140 (still wide), swept, merged to
     100 + 100 (byte labels from here), swept -- state equal to the oracle's after every call; what wide mode does not
