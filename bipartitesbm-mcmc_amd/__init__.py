@@ -64,6 +64,7 @@ ABI = {
     "bisbm_marginals_reset": (C.c_int, [C.c_void_p]),
     "bisbm_marginals_get": (C.c_int, [C.c_void_p, _u32p]),
     "bisbm_get_ka_kb": (C.c_int, [C.c_void_p, _u32p, _u32p]),
+    "bisbm_get_ka_kb_chain": (C.c_int, [C.c_void_p, C.c_uint32, _u32p, _u32p]),
     "bisbm_agg_merge": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "bisbm_agg_merge_total": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "bisbm_get_sizes": (C.c_int, [C.c_void_p, _u64p, _u64p, _u32p, _u32p]),
@@ -291,6 +292,7 @@ class BlockModel:
         self.n = self.na + self.nb
         self.KA, self.KB = int(KA), int(KB)
         self.K = self.KA + self.KB
+        self.mixed_shapes = False  # True once a one-argument agg_merge left the chains with different block counts
         self.epsilon = float(epsilon)
         self.n_chains = int(n_chains)
         self.device = int(device)
@@ -361,8 +363,14 @@ class BlockModel:
         self._check(self._L.bisbm_get_memberships(self._h, int(chain), _p(out, _u32p)))
         return out
 
+    def ka_kb(self, chain=0):
+        """(KA, KB) of one chain: after a one-argument agg_merge the chains of a model may have different block counts."""
+        ka, kb = C.c_uint32(), C.c_uint32()
+        self._check(self._L.bisbm_get_ka_kb_chain(self._h, int(chain), C.byref(ka), C.byref(kb)))
+        return ka.value, kb.value
+
     def _block_state(self, chain, want):
-        K, D = self.K, self.max_degree + 1
+        K, D = sum(self.ka_kb(chain)), self.max_degree + 1
         m = np.zeros((K, K), dtype=np.int32) if "m" in want else None
         m_r = np.zeros(K, dtype=np.int32) if "m_r" in want else None
         n_r = np.zeros(K, dtype=np.int32) if "n_r" in want else None
@@ -405,9 +413,11 @@ class BlockModel:
 
     # -- agglomerative merges between anneals (blockmodel.cc:109-271)
     def _refresh_k(self):
-        ka, kb = C.c_uint32(), C.c_uint32()
-        self._check(self._L.bisbm_get_ka_kb(self._h, C.byref(ka), C.byref(kb)))
-        self.KA, self.KB = ka.value, kb.value
+        """KA / KB / K of the model: the counts all chains share, or -- once a one-argument agg_merge has left the chains
+        with different ones (``mixed_shapes``) -- those of chain 0; ``ka_kb(chain)`` is always per chain."""
+        shapes = {self.ka_kb(c) for c in range(self.n_chains)} if self.n_chains <= 4096 else {self.ka_kb(0)}
+        self.mixed_shapes = len(shapes) > 1
+        self.KA, self.KB = self.ka_kb(0)
         self.K = self.KA + self.KB
 
     def agg_merge(self, diff_a, diff_b=None, nm=10):

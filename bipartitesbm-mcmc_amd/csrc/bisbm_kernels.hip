@@ -559,7 +559,7 @@ __global__ __launch_bounds__(kWave) void sweep_kernel(SweepParams p) {
     }
 
     Tables tab{p.lgamma_tab, p.lgamma_size, p.q_tab, p.q_stride, p.log_tab};
-    const uint32_t chain_gid = p.first_chain_id + chain;
+    const uint32_t chain_gid = chain_gid_of(p, chain);
     const uint64_t num_nodes = p.n;
     const uint64_t all_sweeps = p.duration / num_nodes;
     uint64_t accepted_steps = 0, u = 0, sweeps_done = 0;
@@ -819,7 +819,7 @@ __global__ void shuffle_philox_kernel(ShuffleParams p) {
     const uint32_t chain = blockIdx.y;
     const LabelT* src = (const LabelT*)p.labels_old + (size_t)chain * p.label_stride;
     LabelT* dst = (LabelT*)p.labels + (size_t)chain * p.label_stride;
-    const uint32_t gid = p.first_chain_id + chain;
+    const uint32_t gid = chain_gid_of(p, chain);
     const uint32_t epoch = p.scalars[chain].shuffle_epoch;
     Feistel fa, fb;
     fa.init(phx_draw(p.seed, gid, PHX_INIT_SHUFFLE, ((uint64_t)0 << 32) | epoch), p.na);
@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(256) void split_eval_kernel(SplitParams p) {
         nr[b] = nb;
         if (!p.bits && nb > 1) {
             const uint64_t idx = ((uint64_t)epoch << 32) | ((uint64_t)(b_lo + b) << 16) | (uint64_t)trial;
-            cut[b].f.init(phx_draw(p.seed, p.first_chain_id + chain, PHX_SPLIT, idx), nb);
+            cut[b].f.init(phx_draw(p.seed, chain_gid_of(p, chain), PHX_SPLIT, idx), nb);
             cut[b].half = nb / 2;
         }
     }
@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(256) void split_apply_kernel(SplitParams p) {
         s_nb = (uint32_t)n_r[block];
         if (!p.bits) {
             const uint64_t idx = ((uint64_t)p.scalars[chain].split_epoch << 32) | ((uint64_t)(b_lo + block) << 16) | (uint64_t)trial;
-            cut.f.init(phx_draw(p.seed, p.first_chain_id + chain, PHX_SPLIT, idx), s_nb);
+            cut.f.init(phx_draw(p.seed, chain_gid_of(p, chain), PHX_SPLIT, idx), s_nb);
             cut.half = s_nb / 2;
         }
     }

@@ -36,6 +36,7 @@ struct SweepParams {
     double epsilon;
     // chains
     uint32_t n_chains, first_chain_id;
+    const uint32_t* chain_gids;  // global id of every chain of the launch (keys its Philox streams); NULL: first_chain_id + index
     uint8_t* labels;
     size_t label_stride;
     uint32_t* vlist;  // compat: [chain][n]
@@ -89,6 +90,7 @@ struct BuildParams {
 
 struct ShuffleParams {
     uint32_t n, na, nb, n_chains, first_chain_id;
+    const uint32_t* chain_gids;  // see SweepParams
     uint64_t seed;
     uint8_t* labels;
     const uint8_t* labels_old;  // Philox: snapshot the gather reads from
@@ -124,6 +126,7 @@ struct SplitParams {
     const uint32_t* rowptr;
     const uint32_t* col;
     uint32_t n, na, ka, kb, n_chains, first_chain_id;
+    const uint32_t* chain_gids;  // see SweepParams
     uint32_t type;              // 0: a type-a block is split, 1: a type-b block
     uint32_t trial0, n_trials;  // trials evaluated by this launch: trial0 .. trial0 + n_trials - 1
     uint32_t nm;                // trials per block of the whole call (stride of `bits`)
@@ -144,6 +147,12 @@ constexpr uint32_t PHX_SPLIT = 6;
 hipError_t launch_split_rank(const SplitParams& p, hipStream_t stream);
 hipError_t launch_split_eval(const SplitParams& p, hipStream_t stream);
 hipError_t launch_split_apply(const SplitParams& p, hipStream_t stream);
+
+// global id of chain `chain` of a launch
+template <class P>
+__device__ __forceinline__ uint32_t chain_gid_of(const P& p, uint32_t chain) {
+    return p.chain_gids ? p.chain_gids[chain] : p.first_chain_id + chain;
+}
 
 // metropolis_hasting.cc:10-37, arithmetic types as the C++ promotes them
 __device__ __forceinline__ double temperature_of(const SweepParams& p, uint64_t t) {

@@ -219,6 +219,17 @@ struct bisbm_engine {
     // last sweep timing
     double last_kernel_ms = 0;
     uint64_t last_updates = 0;
+    // Chains with different block counts (after a one-argument agg_merge, blockmodel.cc:208-271: every run ends where it
+    // ends).  Kernels are launched for one (KA, KB), so the handle then becomes a CONTAINER: its chains live in
+    // sub-engines, one per distinct shape (`groups`), which borrow the graph and the tables from it (`root`); chain c of
+    // the handle is chain where[c].second of group where[c].first.  A sub-engine knows the global id of each of its
+    // chains (`gids`, the key of the Philox streams) and its index in the handle (`ridx`).
+    std::vector<bisbm_engine*> groups;
+    std::vector<std::pair<uint32_t, uint32_t>> where;
+    bisbm_engine* root = nullptr;
+    std::vector<uint32_t> gids, ridx;
+    uint32_t* d_gids = nullptr;
+    uint32_t gid(size_t c) const { return gids.empty() ? first_chain_id + (uint32_t)c : gids[c]; }
 };
 
 namespace {
@@ -247,13 +258,30 @@ hipError_t dalloc(T** p, size_t count) {
     return hipMalloc((void**)p, sizeof(T) * std::max<size_t>(count, 1));
 }
 
+void free_chain_arrays(bisbm_engine* h) {
+    void** ptrs[] = {(void**)&h->d_labels, (void**)&h->d_labels_tmp, (void**)&h->d_vlist, (void**)&h->d_m, (void**)&h->d_m_r,
+                     (void**)&h->d_n_r, (void**)&h->d_eta, (void**)&h->d_scalars, (void**)&h->d_mt_engine, (void**)&h->d_mt_gen,
+                     (void**)&h->d_tmp_f64, (void**)&h->d_counts, (void**)&h->d_gids};
+    for (void** p : ptrs)
+        if (*p) {
+            (void)hipFree(*p);
+            *p = nullptr;
+        }
+}
+
 void free_all(bisbm_engine* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    void* ptrs[] = {h->d_rowptr, h->d_col,       h->d_labels, h->d_labels_tmp, h->d_vlist,     h->d_m,
-                    h->d_m_r,    h->d_n_r,       h->d_eta,    h->d_scalars,    h->d_mt_engine, h->d_mt_gen,
-                    h->d_lgamma, h->d_logtab, h->d_q,         h->d_T,      h->d_tmp_f64,    h->d_stage_u32, h->d_counts,
-                    h->d_simd_claims};
+    for (bisbm_engine* g : h->groups) {
+        free_all(g);
+        delete g;
+    }
+    h->groups.clear();
+    free_chain_arrays(h);
+    if (h->root) {  // a sub-engine: the graph and the tables belong to the handle it serves
+        h->d_rowptr = nullptr, h->d_col = nullptr, h->d_lgamma = nullptr, h->d_logtab = nullptr, h->d_q = nullptr;
+    }
+    void* ptrs[] = {h->d_rowptr, h->d_col, h->d_lgamma, h->d_logtab, h->d_q, h->d_T, h->d_stage_u32, h->d_simd_claims};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -287,6 +315,30 @@ int rebuild_state(bisbm_engine* h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->state_ready = true;
     return BISBM_OK;
+}
+
+// container handles (bisbm_engine::groups): run `f` on every group, first error wins
+template <class F>
+int each_group(bisbm_engine* h, F f) {
+    for (bisbm_engine* g : h->groups) {
+        const int rc = f(g);
+        if (rc) {
+            h->err = g->err;
+            return rc;
+        }
+    }
+    return BISBM_OK;
+}
+// ... and gather one value per chain from the groups into the handle's chain order
+template <class T, class F>
+int gather_groups(bisbm_engine* h, T* out, F f) {
+    return each_group(h, [&](bisbm_engine* g) {
+        std::vector<T> tmp(g->n_chains);
+        const int rc = f(g, tmp.data());
+        if (rc == BISBM_OK && out)
+            for (size_t j = 0; j < tmp.size(); ++j) out[g->ridx[j]] = tmp[j];
+        return rc;
+    });
 }
 
 }  // namespace
@@ -471,6 +523,7 @@ int bisbm_destroy(bisbm_handle h) {
 
 int bisbm_set_stream(bisbm_handle h, void* hip_stream) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    for (bisbm_engine* g : h->groups) g->stream = hip_stream ? (hipStream_t)hip_stream : g->own_stream;
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return BISBM_OK;
 }
@@ -480,6 +533,13 @@ int bisbm_set_memberships(bisbm_handle h, int64_t chain, const uint32_t* labels)
     if (!labels) return fail(h, BISBM_ERR_INVALID_ARG, "labels is NULL");
     if (chain != BISBM_ALL_CHAINS && (chain < 0 || chain >= (int64_t)h->n_chains))
         return fail(h, BISBM_ERR_INVALID_ARG, "chain %lld out of range", (long long)chain);
+    if (!h->groups.empty()) {  // (the labels must name blocks of the chain's own shape)
+        if (chain == BISBM_ALL_CHAINS) return each_group(h, [&](bisbm_engine* g) { return bisbm_set_memberships(g, BISBM_ALL_CHAINS, labels); });
+        bisbm_engine* g = h->groups[h->where[chain].first];
+        const int rc = bisbm_set_memberships(g, h->where[chain].second, labels);
+        if (rc) h->err = g->err;
+        return rc;
+    }
     for (uint64_t v = 0; v < h->n; ++v) {
         const uint32_t b = labels[v];
         const bool ok = v < h->na ? b < h->ka : (b >= h->ka && b < h->K);
@@ -497,12 +557,14 @@ int bisbm_set_memberships(bisbm_handle h, int64_t chain, const uint32_t* labels)
 
 int bisbm_init(bisbm_handle h) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!h->groups.empty()) return each_group(h, [](bisbm_engine* g) { return bisbm_init(g); });
     HIPCHK(h, hipSetDevice(h->device));
     return rebuild_state(h);
 }
 
 int bisbm_shuffle(bisbm_handle h) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!h->groups.empty()) return each_group(h, [](bisbm_engine* g) { return bisbm_shuffle(g); });
     HIPCHK(h, hipSetDevice(h->device));
     ShuffleParams sp{};
     sp.n = (uint32_t)h->n;
@@ -510,6 +572,7 @@ int bisbm_shuffle(bisbm_handle h) {
     sp.nb = (uint32_t)h->nb;
     sp.n_chains = h->n_chains;
     sp.first_chain_id = h->first_chain_id;
+    sp.chain_gids = h->d_gids;
     sp.seed = h->seed;
     sp.labels = h->d_labels;
     sp.labels_old = h->d_labels_tmp;
@@ -530,6 +593,16 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     if (!kwargs) return fail(h, BISBM_ERR_INVALID_ARG, "kwargs is NULL");
     if (schedule < BISBM_SCHED_EXPONENTIAL || schedule > BISBM_SCHED_ABRUPT_COOL)
         return fail(h, BISBM_ERR_INVALID_ARG, "unknown schedule %d", schedule);
+    if (!h->groups.empty()) {  // one launch per shape, one after the other
+        h->last_kernel_ms = 0;
+        h->last_updates = 0;
+        return gather_groups<double>(h, acc_rate_out, [&](bisbm_engine* g, double* r) {
+            const int rc = bisbm_anneal(g, schedule, kwargs, duration_steps, steps_await, r);
+            h->last_kernel_ms += g->last_kernel_ms;
+            h->last_updates += g->last_updates;
+            return rc;
+        });
+    }
     if (!h->state_ready) return fail(h, BISBM_ERR_STATE, "call bisbm_init or bisbm_shuffle before bisbm_anneal");
     HIPCHK(h, hipSetDevice(h->device));
 
@@ -545,6 +618,7 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     p.epsilon = h->epsilon;
     p.n_chains = h->n_chains;
     p.first_chain_id = h->first_chain_id;
+    p.chain_gids = h->d_gids;
     p.labels = h->d_labels;
     p.label_stride = h->label_stride;
     p.wide = h->wide ? 1u : 0u;
@@ -681,6 +755,12 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
 int bisbm_get_memberships(bisbm_handle h, uint32_t chain, uint32_t* labels_out) {
     if (!h) return BISBM_ERR_INVALID_ARG;
     if (!labels_out || chain >= h->n_chains) return fail(h, BISBM_ERR_INVALID_ARG, "bad chain or NULL output");
+    if (!h->groups.empty()) {
+        bisbm_engine* g = h->groups[h->where[chain].first];
+        const int rc = bisbm_get_memberships(g, h->where[chain].second, labels_out);
+        if (rc) h->err = g->err;
+        return rc;
+    }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, launch_labels_widen(h->d_labels + (size_t)chain * h->label_stride * h->lbytes(), h->wide, h->d_stage_u32, (uint32_t)h->n, h->stream));
     HIPCHK(h, hipMemcpyAsync(labels_out, h->d_stage_u32, sizeof(uint32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
@@ -691,6 +771,12 @@ int bisbm_get_memberships(bisbm_handle h, uint32_t chain, uint32_t* labels_out) 
 int bisbm_get_block_state(bisbm_handle h, uint32_t chain, int32_t* m, int32_t* m_r, int32_t* n_r, uint32_t* eta) {
     if (!h) return BISBM_ERR_INVALID_ARG;
     if (chain >= h->n_chains) return fail(h, BISBM_ERR_INVALID_ARG, "chain out of range");
+    if (!h->groups.empty()) {  // (array sizes follow the chain's own shape: bisbm_get_ka_kb_chain)
+        bisbm_engine* g = h->groups[h->where[chain].first];
+        const int rc = bisbm_get_block_state(g, h->where[chain].second, m, m_r, n_r, eta);
+        if (rc) h->err = g->err;
+        return rc;
+    }
     if (!h->state_ready) return fail(h, BISBM_ERR_STATE, "block state not built yet");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -714,6 +800,7 @@ int bisbm_get_block_state(bisbm_handle h, uint32_t chain, int32_t* m, int32_t* m
 int bisbm_get_cum_dS(bisbm_handle h, double* out) {
     if (!h) return BISBM_ERR_INVALID_ARG;
     if (!out) return fail(h, BISBM_ERR_INVALID_ARG, "out is NULL");
+    if (!h->groups.empty()) return gather_groups<double>(h, out, [](bisbm_engine* g, double* o) { return bisbm_get_cum_dS(g, o); });
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<ChainScalars> sc(h->n_chains);
@@ -724,6 +811,10 @@ int bisbm_get_cum_dS(bisbm_handle h, double* out) {
 
 int bisbm_get_last_counts(bisbm_handle h, uint64_t* accepted, uint64_t* sweeps) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!h->groups.empty()) {
+        const int rc = gather_groups<uint64_t>(h, accepted, [](bisbm_engine* g, uint64_t* o) { return bisbm_get_last_counts(g, o, nullptr); });
+        return rc ? rc : gather_groups<uint64_t>(h, sweeps, [](bisbm_engine* g, uint64_t* o) { return bisbm_get_last_counts(g, nullptr, o); });
+    }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<ChainScalars> sc(h->n_chains);
@@ -738,6 +829,7 @@ int bisbm_get_last_counts(bisbm_handle h, uint64_t* accepted, uint64_t* sweeps) 
 int bisbm_entropy(bisbm_handle h, double* out) {
     if (!h) return BISBM_ERR_INVALID_ARG;
     if (!out) return fail(h, BISBM_ERR_INVALID_ARG, "out is NULL");
+    if (!h->groups.empty()) return gather_groups<double>(h, out, [](bisbm_engine* g, double* o) { return bisbm_entropy(g, o); });
     if (!h->state_ready) return fail(h, BISBM_ERR_STATE, "block state not built yet");
     HIPCHK(h, hipSetDevice(h->device));
     EntropyParams ep{};
@@ -777,6 +869,7 @@ int bisbm_entropy(bisbm_handle h, double* out) {
 
 int bisbm_marginals_reset(bisbm_handle h) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!h->groups.empty()) return fail(h, BISBM_ERR_STATE, "the chains of this handle have different block counts: no common marginal histogram");
     HIPCHK(h, hipSetDevice(h->device));
     const uint32_t kmax = std::max(h->ka, h->kb);
     const size_t cnt = (size_t)h->n * kmax;
@@ -796,6 +889,7 @@ int bisbm_marginals_reset(bisbm_handle h) {
 
 int bisbm_marginals_accumulate(bisbm_handle h, uint32_t* device_counts) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!h->groups.empty()) return fail(h, BISBM_ERR_STATE, "the chains of this handle have different block counts: no common marginal histogram");
     if (h->wide) return fail(h, BISBM_ERR_UNSUPPORTED, "marginal histograms are kept for at most 256 blocks (KA + KB = %u)", h->K);
     HIPCHK(h, hipSetDevice(h->device));
     if (!device_counts) {
@@ -835,6 +929,8 @@ int bisbm_marginals_get(bisbm_handle h, uint32_t* counts_out) {
 
 int bisbm_get_ka_kb(bisbm_handle h, uint32_t* ka, uint32_t* kb) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!h->groups.empty())
+        return fail(h, BISBM_ERR_STATE, "the chains of this handle have different block counts: ask per chain (bisbm_get_ka_kb_chain)");
     if (ka) *ka = h->ka;
     if (kb) *kb = h->kb;
     return BISBM_OK;
@@ -1205,6 +1301,7 @@ int run_split(bisbm_engine* h, int type, int nm) {
     sp.kb = h->kb;
     sp.n_chains = h->n_chains;
     sp.first_chain_id = h->first_chain_id;
+    sp.chain_gids = h->d_gids;
     sp.type = (uint32_t)type;
     sp.nm = (uint32_t)nm;
     sp.seed = h->seed;
@@ -1369,7 +1466,9 @@ int run_split(bisbm_engine* h, int type, int nm) {
 }
 
 // which: 0 = agg_merge(diff_a, diff_b, nm), 1 = agg_merge(diff, nm)
-int run_merges(bisbm_engine* h, int which, int diff_a, int diff_b, int nm) {
+constexpr int kDiverged = 1000;  // run_merges: the chains ended with different block counts (labels relabelled, state NOT rebuilt)
+
+int run_merges(bisbm_engine* h, int which, int diff_a, int diff_b, int nm, std::vector<std::pair<size_t, size_t>>* ends_out = nullptr) {
     if (!h->state_ready) return fail(h, BISBM_ERR_STATE, "call bisbm_init or bisbm_shuffle before bisbm_agg_merge");
     if (nm < 1) return fail(h, BISBM_ERR_INVALID_ARG, "nm must be >= 1");
     if (which == 0) {  // blockmodel.cc:110-117: negative diffs are splits, one block at a time, type a first
@@ -1471,7 +1570,7 @@ int run_merges(bisbm_engine* h, int which, int diff_a, int diff_b, int nm) {
         for (size_t i = 0; i < K0; ++i) mc.cmap[i] = (uint16_t)i;
         mc.compat = compat;
         mc.seed = h->seed;
-        mc.chain_gid = h->first_chain_id + (uint32_t)c;
+        mc.chain_gid = h->gid(c);
         mc.epoch = sc[c].merge_epoch;
         mc.epsilon = h->epsilon;
         mc.lg = &h->tab->lg;
@@ -1512,12 +1611,16 @@ int run_merges(bisbm_engine* h, int which, int diff_a, int diff_b, int nm) {
                         c);
         }
     const size_t nka = ends[0].first, nkb = ends[0].second;
+    bool diverged = false;
     for (size_t c = 1; c < C; ++c)
         if (ends[c] != ends[0]) {
-            cleanup();
-            return fail(h, BISBM_ERR_STATE,
-                        "chains ended with different block counts (chain 0: %zu+%zu, chain %zu: %zu+%zu); one (Ka,Kb) per handle",
-                        nka, nkb, c, ends[c].first, ends[c].second);
+            if (!ends_out) {
+                cleanup();
+                return fail(h, BISBM_ERR_STATE,
+                            "chains ended with different block counts (chain 0: %zu+%zu, chain %zu: %zu+%zu); one (Ka,Kb) per handle",
+                            nka, nkb, c, ends[c].first, ends[c].second);
+            }
+            diverged = true;
         }
     if (h->wide) {
         MCHK(hipMemcpy(d_map, fmap.data(), sizeof(uint16_t) * fmap.size(), hipMemcpyHostToDevice));
@@ -1534,6 +1637,11 @@ int run_merges(bisbm_engine* h, int which, int diff_a, int diff_b, int nm) {
     MCHK(hipStreamSynchronize(h->stream));
 #undef MCHK
     cleanup();
+    if (diverged) {  // every chain's labels are in its own new numbering; the caller regroups the chains by shape
+        *ends_out = ends;
+        h->state_ready = false;
+        return kDiverged;
+    }
     h->ka = (uint32_t)nka;
     h->kb = (uint32_t)nkb;
     h->K = h->ka + h->kb;
@@ -1556,12 +1664,178 @@ int run_merges(bisbm_engine* h, int which, int diff_a, int diff_b, int nm) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// chains with different block counts: sub-engines per shape (see bisbm_engine::groups)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// a sub-engine of `root` for `count` chains of shape (ka, kb): own per-chain arrays, stream and events; graph and tables borrowed
+bisbm_engine* new_group(bisbm_engine* root, uint32_t ka, uint32_t kb, uint32_t count, std::string& err) {
+    std::unique_ptr<bisbm_engine> gp(new bisbm_engine());
+    bisbm_engine* g = gp.get();
+    g->root = root;
+    g->device = root->device;
+    g->n = root->n, g->na = root->na, g->nb = root->nb, g->num_edges = root->num_edges, g->nnz = root->nnz;
+    g->ka = ka, g->kb = kb, g->K = ka + kb, g->maxdeg = root->maxdeg, g->n_chains = count;
+    g->cap_ka = ka, g->cap_kb = kb;
+    g->wide = g->K > 256;
+    g->epsilon = root->epsilon, g->rng_mode = root->rng_mode, g->seed = root->seed, g->gen_seed = root->gen_seed;
+    g->label_stride = root->label_stride;
+    g->d_rowptr = root->d_rowptr, g->d_col = root->d_col, g->d_lgamma = root->d_lgamma, g->d_logtab = root->d_logtab, g->d_q = root->d_q;
+    g->tab = root->tab, g->q_stride = root->q_stride, g->ent_deg = root->ent_deg, g->ent_multi = root->ent_multi;
+    const size_t C = count, K = g->K, D = (size_t)g->maxdeg + 1;
+    hipError_t e = hipStreamCreateWithFlags(&g->own_stream, hipStreamNonBlocking);
+    g->stream = g->own_stream;
+    if (e == hipSuccess) e = hipEventCreate(&g->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&g->ev1);
+    if (e == hipSuccess) e = dalloc(&g->d_labels, C * g->label_stride * g->lbytes());
+    if (e == hipSuccess) e = dalloc(&g->d_m, C * ka * kb);
+    if (e == hipSuccess) e = dalloc(&g->d_m_r, C * K);
+    if (e == hipSuccess) e = dalloc(&g->d_n_r, C * K);
+    if (e == hipSuccess) e = dalloc(&g->d_eta, C * K * D);
+    if (e == hipSuccess) e = dalloc(&g->d_scalars, C);
+    if (e == hipSuccess) e = dalloc(&g->d_tmp_f64, C);
+    if (e == hipSuccess) e = dalloc(&g->d_stage_u32, (size_t)g->n);
+    if (e == hipSuccess) e = dalloc(&g->d_gids, C);
+    if (e == hipSuccess && g->rng_mode == BISBM_RNG_MT19937_COMPAT) {
+        e = dalloc(&g->d_vlist, C * g->n);
+        if (e == hipSuccess) e = dalloc(&g->d_mt_engine, C * 624);
+        if (e == hipSuccess) e = dalloc(&g->d_mt_gen, C * 624);
+    } else if (e == hipSuccess) {
+        e = dalloc(&g->d_labels_tmp, C * g->label_stride * g->lbytes());
+    }
+    if (e != hipSuccess) {
+        err = std::string("sub-engine allocation: ") + hipGetErrorString(e);
+        free_all(g);
+        return nullptr;
+    }
+    return gp.release();
+}
+
+// The chains of `src` (labels already in each chain's own new numbering, shapes in `ends`) go to new sub-engines of
+// `root`, one per distinct shape in order of first appearance; every chain keeps its generator state, counters and
+// global id.  The new engines are appended to `out` with their state rebuilt.
+int split_by_shape(bisbm_engine* root, bisbm_engine* src, const std::vector<std::pair<size_t, size_t>>& ends,
+                   std::vector<bisbm_engine*>& out) {
+    std::vector<std::pair<size_t, size_t>> shapes;
+    for (auto const& e : ends)
+        if (std::find(shapes.begin(), shapes.end(), e) == shapes.end()) shapes.push_back(e);
+    const size_t n = (size_t)src->n;
+    for (auto const& shape : shapes) {
+        std::vector<uint32_t> members;
+        for (size_t c = 0; c < ends.size(); ++c)
+            if (ends[c] == shape) members.push_back((uint32_t)c);
+        std::string err;
+        bisbm_engine* g = new_group(root, (uint32_t)shape.first, (uint32_t)shape.second, (uint32_t)members.size(), err);
+        if (!g) return fail(root, BISBM_ERR_HIP, "%s", err.c_str());
+        out.push_back(g);
+        for (size_t j = 0; j < members.size(); ++j) {
+            const size_t c = members[j];
+            g->gids.push_back(src->gid(c));
+            g->ridx.push_back(src->ridx.empty() ? (uint32_t)c : src->ridx[c]);
+            const uint8_t* from = src->d_labels + c * src->label_stride * src->lbytes();
+            uint8_t* to = g->d_labels + j * g->label_stride * g->lbytes();
+            hipError_t e;
+            if (src->wide == g->wide)
+                e = hipMemcpyAsync(to, from, n * g->lbytes(), hipMemcpyDeviceToDevice, g->stream);
+            else  // (merges only lower K: a wide source, a byte-label destination)
+                e = launch_labels_narrow(from, to, g->label_stride, (uint32_t)n, 1, g->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(g->d_scalars + j, src->d_scalars + c, sizeof(ChainScalars), hipMemcpyDeviceToDevice, g->stream);
+            if (e == hipSuccess && g->rng_mode == BISBM_RNG_MT19937_COMPAT) {
+                e = hipMemcpyAsync(g->d_mt_engine + j * 624, src->d_mt_engine + c * 624, sizeof(uint32_t) * 624, hipMemcpyDeviceToDevice, g->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(g->d_mt_gen + j * 624, src->d_mt_gen + c * 624, sizeof(uint32_t) * 624, hipMemcpyDeviceToDevice, g->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(g->d_vlist + j * n, src->d_vlist + c * n, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, g->stream);
+            }
+            if (e != hipSuccess) return fail(root, BISBM_ERR_HIP, "moving chain %zu to its group: %s", c, hipGetErrorString(e));
+        }
+        hipError_t e = hipMemcpyAsync(g->d_gids, g->gids.data(), sizeof(uint32_t) * g->gids.size(), hipMemcpyHostToDevice, g->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+        if (e != hipSuccess) return fail(root, BISBM_ERR_HIP, "group setup: %s", hipGetErrorString(e));
+        const int rc = rebuild_state(g);
+        if (rc) return fail(root, rc, "%s", g->err.c_str());
+    }
+    return BISBM_OK;
+}
+
+void remap_groups(bisbm_engine* root) {
+    root->where.assign(root->n_chains, {0u, 0u});
+    for (size_t gi = 0; gi < root->groups.size(); ++gi)
+        for (size_t j = 0; j < root->groups[gi]->ridx.size(); ++j) root->where[root->groups[gi]->ridx[j]] = {(uint32_t)gi, (uint32_t)j};
+}
+
+// agg_merge(engine, diff, nm) on a handle whose chains may end (or already live) in different shapes
+int merge_total_grouped(bisbm_engine* h, int diff, int nm) {
+    std::vector<std::pair<size_t, size_t>> ends;
+    if (h->groups.empty()) {
+        const int rc = run_merges(h, 1, diff, 0, nm, &ends);
+        if (rc != kDiverged) return rc;
+        std::vector<bisbm_engine*> fresh;
+        const int rc2 = split_by_shape(h, h, ends, fresh);
+        if (rc2) {
+            for (bisbm_engine* g : fresh) {
+                free_all(g);
+                delete g;
+            }
+            return rc2;
+        }
+        h->groups = fresh;
+        free_chain_arrays(h);  // the chains live in the groups now
+        h->state_ready = true;
+        remap_groups(h);
+        return BISBM_OK;
+    }
+    std::vector<bisbm_engine*> next;
+    int rc_all = BISBM_OK;
+    for (bisbm_engine* g : h->groups) {
+        if (rc_all) {
+            next.push_back(g);
+            continue;
+        }
+        const int rc = run_merges(g, 1, diff, 0, nm, &ends);
+        if (rc == BISBM_OK) {
+            next.push_back(g);
+        } else if (rc == kDiverged) {
+            rc_all = split_by_shape(h, g, ends, next);
+            free_all(g);
+            delete g;
+        } else {
+            h->err = g->err;
+            rc_all = rc;
+            next.push_back(g);
+        }
+    }
+    h->groups = next;
+    remap_groups(h);
+    return rc_all;
+}
+
+}  // namespace
+
 int bisbm_agg_merge(bisbm_handle h, int diff_a, int diff_b, int nm) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!h->groups.empty()) {  // the same change of counts in every group: each keeps one shape
+        for (bisbm_engine* g : h->groups) {
+            const int rc = run_merges(g, 0, diff_a, diff_b, nm);
+            if (rc) {
+                h->err = g->err;
+                return rc;
+            }
+        }
+        return BISBM_OK;
+    }
     return run_merges(h, 0, diff_a, diff_b, nm);
 }
 
 int bisbm_agg_merge_total(bisbm_handle h, int diff, int nm) {
     if (!h) return BISBM_ERR_INVALID_ARG;
-    return run_merges(h, 1, diff, 0, nm);
+    return merge_total_grouped(h, diff, nm);
+}
+
+int bisbm_get_ka_kb_chain(bisbm_handle h, uint32_t chain, uint32_t* ka, uint32_t* kb) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    if (chain >= h->n_chains) return fail(h, BISBM_ERR_INVALID_ARG, "chain out of range");
+    const bisbm_engine* e = h->groups.empty() ? h : h->groups[h->where[chain].first];
+    if (ka) *ka = e->ka;
+    if (kb) *kb = e->kb;
+    return BISBM_OK;
 }

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     const double eps = p.epsilon;
     const double Kd = (double)K;
     const double epsK = eps * Kd;
-    const uint32_t chain_gid = p.first_chain_id + chain;
+    const uint32_t chain_gid = chain_gid_of(p, chain);
     const uint32_t n = p.n;
     const uint64_t all_sweeps = p.duration / n;
     const double T_const = (double)p.kw0;  // CT: constant schedule (metropolis_hasting.cc:25-28)

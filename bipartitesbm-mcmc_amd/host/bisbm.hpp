@@ -208,6 +208,12 @@ public:
         check(bisbm_agg_merge_total(h_, diff, nm));
         refresh_k();
     }
+    // block counts of one chain (the one-argument agg_merge lets every chain end with its own, blockmodel.cc:208-271)
+    std::pair<size_t, size_t> ka_kb(uint32_t chain) const {
+        uint32_t ka = 0, kb = 0;
+        check(bisbm_get_ka_kb_chain(h_, chain, &ka, &kb));
+        return {ka, kb};
+    }
     size_t get_KA() const noexcept { return KA_; }
     size_t get_KB() const noexcept { return KB_; }
     int get_num_edges() const {
@@ -258,7 +264,7 @@ private:
     }
     void refresh_k() {
         uint32_t ka = 0, kb = 0;
-        check(bisbm_get_ka_kb(h_, &ka, &kb));
+        check(bisbm_get_ka_kb_chain(h_, 0, &ka, &kb));  // (chain 0's: after agg_merge(diff, nm) chains may differ, see ka_kb())
         KA_ = ka;
         KB_ = kb;
     }

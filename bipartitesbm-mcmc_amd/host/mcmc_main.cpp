@@ -449,9 +449,11 @@ int main(int argc, char const* argv[]) {
         try {
             std::iota(memberships_init.begin(), memberships_init.end(), 0);  // every node its own block (:350)
             if (nature && opt.n_chains > 1) {
-                // agg_merge(engine, diff, nm) lets every run end with its own (Ka,Kb) (blockmodel.cc:208-271) and a handle
-                // has one block count for all its chains: --nature --chains N runs the N chains one after the other, each
-                // in a handle of its own with its global chain id (same streams as in one handle), and prints the best
+                // agg_merge(engine, diff, nm) lets every run end with its own (Ka,Kb) (blockmodel.cc:208-271), and in this
+                // driver every run also has its own stage sizes (ceil of ITS block count) and its own last stage: --nature
+                // --chains N therefore runs the N chains one after the other, each in a handle of its own with its global
+                // chain id (same streams as in one handle), and prints the best.  (One handle does serve chains of
+                // different shapes -- bisbm_agg_merge_total -- but applies one diff to all of them per call.)
                 double best_dl = std::numeric_limits<double>::infinity();
                 uint_vec_t best_labels;
                 size_t best_ka = 0, best_kb = 0, best_chain = 0;

@@ -138,21 +138,24 @@ int bisbm_marginals_get(bisbm_handle h, uint32_t *counts_out /* n*kmax, host */)
  * labels move up by one) or block K (type b).  The reference's split dS indexes its split vector with a counter that
  * runs over all nodes (:402), an out-of-range read; the engine implements the intended meaning -- position = rank of
  * the node within its block -- which is what agg_split's own pass (:554-561) uses.
- * One (Ka,Kb) per handle: the two-type overload changes every chain's counts by the same amounts.  The selection is
+ * The two-type overload changes every chain's counts by the same amounts.  The selection is
  * K-scale host work, as in the reference; ranks, cut evaluation, relabelling and the rebuild run on the device.
  * BISBM_ERR_UNSUPPORTED when a split would exceed 256 blocks, BISBM_ERR_STATE when no block can be split. */
 int bisbm_agg_merge(bisbm_handle h, int diff_a, int diff_b, int nm);
 
 /* blockmodel_t::agg_merge(engine, diff, nm) (blockmodel.cc:208-271; call site mcmc_main.cc:365): diff merges over
  * both types together, proposals redrawn while the last one taken had dS = +inf.  Which types lose blocks is up to
- * each chain's own proposals: when the chains of a handle end with different (Ka,Kb) the call fails with
- * BISBM_ERR_STATE and leaves the state as it was (one block count per handle: the kernels are launched for one
- * shape) -- run --nature style schedules with one chain per handle, or use the two-type overload.  diff < 0 is
- * BISBM_ERR_INVALID_ARG (this overload has no split branch). */
+ * each chain's own proposals, so the chains of a handle may end with different (Ka,Kb).  The handle then keeps them
+ * grouped by shape internally (kernels are launched for one shape: one launch per group from then on); every call
+ * keeps working per chain -- anneal, memberships, block state (array sizes follow bisbm_get_ka_kb_chain), sum dS,
+ * entropy, further merges of either overload -- except the ones that need one common shape: bisbm_get_ka_kb and the
+ * marginal histogram return BISBM_ERR_STATE.  diff < 0 is BISBM_ERR_INVALID_ARG (this overload has no split branch). */
 int bisbm_agg_merge_total(bisbm_handle h, int diff, int nm);
 
-/* Shape queries (get_KA/get_KB blockmodel.cc:103-105, get_num_edges :81). */
+/* Shape queries (get_KA/get_KB blockmodel.cc:103-105, get_num_edges :81).  bisbm_get_ka_kb: the block counts all chains
+ * share (BISBM_ERR_STATE once a one-argument agg_merge left them with different ones); bisbm_get_ka_kb_chain: one chain's. */
 int bisbm_get_ka_kb(bisbm_handle h, uint32_t *ka, uint32_t *kb);
+int bisbm_get_ka_kb_chain(bisbm_handle h, uint32_t chain, uint32_t *ka, uint32_t *kb);
 int bisbm_get_sizes(bisbm_handle h, uint64_t *n, uint64_t *num_edges, uint32_t *max_degree,
                     uint32_t *n_chains);
 

@@ -2,6 +2,7 @@
   * the golden reference outputs recorded by the survey (mt19937-compat mode, bit-exact),
   * the oracle restatement on the same seeded inputs (both RNG modes, integers bit-exact),
   * size-independent properties at BASELINE.json's full size."""
+import ctypes as C
 import importlib
 import math
 import os
@@ -491,48 +492,70 @@ def test_agg_split_many_chains_philox():
         t.agg_merge(-1, 0, 5)
 
 
-def test_agg_merge_total_refuses_diverging_chains():
-    """agg_merge(engine, diff, nm) lets every run end with its own (Ka,Kb) (blockmodel.cc:208-271); a handle has one
-    block count for all its chains, so diverging chains are refused (BISBM_ERR_STATE) and nothing is changed; one chain
-    per handle (the CLI's --nature) always works."""
+@pytest.mark.parametrize("mode", ["philox", "compat"])
+def test_chains_may_end_with_different_block_counts(mode):
+    """agg_merge(engine, diff, nm) lets every run end with its own (Ka,Kb) (blockmodel.cc:208-271).  The handle then keeps
+    its chains grouped by shape: every chain stays equal to its own oracle run through a sweep, a second one-argument
+    merge (groups split further), a two-argument merge and another sweep; per-chain shapes, states, rates, sum dS and
+    description lengths are served, the calls that need one common shape say so."""
     rowptr, col, na, nb = O.load_graph("n_1000")
     n = na + nb
     labels = O.contiguous_labels(na, nb, 8, 9)
-    chains = 32
-    g = gpu_model(rowptr, col, na, nb, 8, 9, 1.0, labels, n_chains=chains, rng="philox", seed=123)
+    chains = 12
+    g = gpu_model(rowptr, col, na, nb, 8, 9, 1.0, labels, n_chains=chains, rng=mode, seed=123, gen_seed=77)
     g.shuffle_bisbm()
     mh = B.MetropolisHasting()
     mh.anneal(g, "constant", [1.0], 3 * n, BIG)  # (right after a shuffle every chain merges type b only)
-    ends = set()
+    os_ = []
     for c in range(chains):
         o = O.OracleModel(rowptr, col, na, nb, 8, 9, 1.0, labels)
-        o.seed_philox(123, c)
+        if mode == "philox":
+            o.seed_philox(123, c)
+        else:
+            o.seed_compat(123 + c, 77 + c)
         o.shuffle_bisbm()
         o.anneal("constant", [1.0], 3 * n, BIG)
+        os_.append(o)
+
+    def check():
+        for c, o in enumerate(os_):
+            assert g.ka_kb(c) == (o.ka, o.kb)
+            assert_state_equal(g, o, c)
+        ent, cum = g.entropy(), g.get_entropy()
+        for c, o in enumerate(os_):
+            assert abs(ent[c] - o.entropy()) <= 1e-9 * abs(o.entropy())
+            assert abs(cum[c] - o.get_entropy()) <= 1e-9 * max(1.0, abs(o.get_entropy()))
+
+    g.agg_merge(5, None, 10)
+    for o in os_:
         assert o.agg_merge_total(5, 10) == 0
-        ends.add((o.ka, o.kb))
-    assert len(ends) > 1  # the premise: these chains do not agree
-    before = [g.get_memberships(c) for c in (0, 17, 31)]
+    assert len({(o.ka, o.kb) for o in os_}) > 1 and g.mixed_shapes  # the premise: these chains do not agree
+    check()
+    rg = mh.anneal(g, "constant", [1.0], 2 * n, BIG)
+    for c, o in enumerate(os_):
+        assert rg[c] == o.anneal("constant", [1.0], 2 * n, BIG)
+    check()
+    g.agg_merge(3, None, 10)  # groups split further
+    for o in os_:
+        assert o.agg_merge_total(3, 10) == 0
+    check()
+    g.agg_merge(1, 1, 10)  # the two-argument overload: the same change in every group
+    for o in os_:
+        assert o.agg_merge(1, 1, 10) == 0
+    rg = mh.anneal(g, "abrupt_cool", [0.0], n, BIG)
+    for c, o in enumerate(os_):
+        assert rg[c] == o.anneal("abrupt_cool", [0.0], n, BIG)
+    check()
+    # one common shape is gone: the calls that need it say so
+    ka, kb = C.c_uint32(), C.c_uint32()
+    assert g._L.bisbm_get_ka_kb(g._h, C.byref(ka), C.byref(kb)) == B.BISBM_ERR_STATE
     with pytest.raises(B.BisbmError) as e:
-        g.agg_merge(5, None, 10)
+        g.marginals_accumulate(None)
     assert e.value.code == B.BISBM_ERR_STATE
-    assert (g.KA, g.KB) == (8, 9)
-    for c, lab in zip((0, 17, 31), before):
-        assert (g.get_memberships(c) == lab).all()
-    rates = mh.anneal(g, "constant", [1.0], n, BIG)  # the handle is still good
-    assert (rates > 0).all()
-    # the same call on a one-chain handle: the chain's own end point
-    solo = gpu_model(rowptr, col, na, nb, 8, 9, 1.0, labels, n_chains=1, rng="philox", seed=123, first_chain_id=17)
-    solo.shuffle_bisbm()
-    mh.anneal(solo, "constant", [1.0], 3 * n, BIG)
-    solo.agg_merge(5, None, 10)
-    o = O.OracleModel(rowptr, col, na, nb, 8, 9, 1.0, labels)
-    o.seed_philox(123, 17)
-    o.shuffle_bisbm()
-    o.anneal("constant", [1.0], 3 * n, BIG)
-    o.agg_merge_total(5, 10)
-    assert (solo.KA, solo.KB) == (o.ka, o.kb)
-    assert_state_equal(solo, o)
+    # labels can still be set per chain (they must name blocks of that chain's shape), and the state rebuilt
+    g.set_memberships(os_[3].memberships(), chain=3)
+    g.init_bisbm()
+    assert_state_equal(g, os_[3], 3)
 
 
 def test_cli_nature_with_several_chains():
