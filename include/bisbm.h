@@ -21,7 +21,8 @@
 extern "C" {
 #endif
 
-#define BISBM_ABI_VERSION 1
+/* 2: bisbm_get_ka_kb_chain; KA + KB up to 65535 (wide mode); handles whose chains differ in shape.  Additions only. */
+#define BISBM_ABI_VERSION 2
 
 typedef struct bisbm_engine *bisbm_handle;
 

@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound(built):
     for name in sorted(declared):
         assert hasattr(raw, name), "libbisbm_hip.so does not export %s" % name
     assert declared == set(B.ABI), (declared ^ set(B.ABI))
-    assert built.bisbm_abi_version() == 1
+    assert built.bisbm_abi_version() == 2
 
 
 def test_header_cites_the_reference_interface():
