@@ -593,15 +593,32 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     if (!kwargs) return fail(h, BISBM_ERR_INVALID_ARG, "kwargs is NULL");
     if (schedule < BISBM_SCHED_EXPONENTIAL || schedule > BISBM_SCHED_ABRUPT_COOL)
         return fail(h, BISBM_ERR_INVALID_ARG, "unknown schedule %d", schedule);
-    if (!h->groups.empty()) {  // one launch per shape, one after the other
+    if (!h->groups.empty()) {
+        // one launch per shape, all in flight together: every group has a stream of its own, and a host thread per group
+        // makes the (blocking) call; kernel time is reported as the longest group's, updates as the sum
+        const size_t G = h->groups.size();
+        std::vector<int> rcs(G, BISBM_OK);
+        std::vector<std::vector<double>> rates(G);
+        std::vector<std::thread> th;
+        for (size_t gi = 0; gi < G; ++gi) {
+            rates[gi].resize(h->groups[gi]->n_chains);
+            th.emplace_back([&, gi] { rcs[gi] = bisbm_anneal(h->groups[gi], schedule, kwargs, duration_steps, steps_await, rates[gi].data()); });
+        }
+        for (auto& t : th) t.join();
         h->last_kernel_ms = 0;
         h->last_updates = 0;
-        return gather_groups<double>(h, acc_rate_out, [&](bisbm_engine* g, double* r) {
-            const int rc = bisbm_anneal(g, schedule, kwargs, duration_steps, steps_await, r);
-            h->last_kernel_ms += g->last_kernel_ms;
+        for (size_t gi = 0; gi < G; ++gi) {
+            bisbm_engine* g = h->groups[gi];
+            if (rcs[gi]) {
+                h->err = g->err;
+                return rcs[gi];
+            }
+            h->last_kernel_ms = std::max(h->last_kernel_ms, g->last_kernel_ms);
             h->last_updates += g->last_updates;
-            return rc;
-        });
+            if (acc_rate_out)
+                for (size_t j = 0; j < rates[gi].size(); ++j) acc_rate_out[g->ridx[j]] = rates[gi][j];
+        }
+        return BISBM_OK;
     }
     if (!h->state_ready) return fail(h, BISBM_ERR_STATE, "call bisbm_init or bisbm_shuffle before bisbm_anneal");
     HIPCHK(h, hipSetDevice(h->device));

@@ -121,6 +121,58 @@ def test_config4_estimate_mode_512_chains():
     assert ((rates > 0.05) & (rates <= 1.0)).all()
 
 
+def test_estimate_mode_with_the_one_argument_merge_at_full_size():
+    """The same graph, 128 chains from 40 + 40 blocks, two one-argument merges (blockmodel.cc:208-271: every chain decides
+    which type loses blocks, so the chains end in several shapes and the handle regroups them) with greedy sweeps, then a
+    sweep at T = 1 with all groups in flight together.  Sampled chains equal their oracle runs; every chain consistent."""
+    na = nb = 500_000
+    n = na + nb
+    a, b = SYN.planted_edges(na, nb, 10_000_000, 32, 32, seed=1)
+    rowptr, col = B.edge_to_adj((a, b), n)
+    del a, b
+    k0 = 40
+    labels = SYN.contiguous_labels(na, nb, k0, k0)
+    chains = 128
+    g = gpu_model(rowptr, col, na, nb, k0, k0, 1.0, labels, n_chains=chains, rng="philox", seed=77)
+    g.shuffle_bisbm()
+    mh = B.MetropolisHasting()
+    mh.anneal(g, "constant", [1.0], n, BIG)
+    sample = (0, 63, 127)
+    oracles = []
+    for c in sample:
+        o = O.OracleModel(rowptr, col, na, nb, k0, k0, 1.0, labels)
+        o.seed_philox(77, c)
+        o.shuffle_bisbm()
+        o.anneal("constant", [1.0], n, BIG)
+        oracles.append(o)
+    for diff in (9, 7):
+        g.agg_merge(diff, None, 10)
+        rates = mh.anneal(g, "abrupt_cool", [0.0], n, BIG)
+        for o, c in zip(oracles, sample):
+            assert o.agg_merge_total(diff, 10) == 0
+            assert o.anneal("abrupt_cool", [0.0], n, BIG) == rates[c]
+            assert g.ka_kb(c) == (o.ka, o.kb)
+    shapes = {g.ka_kb(c) for c in range(chains)}
+    print("shapes after two one-argument merges:", sorted(shapes))
+    assert len(shapes) > 1 and all(ka + kb == 2 * k0 - 16 for ka, kb in shapes)
+    s0, cum0 = g.entropy(), g.get_entropy()
+    rates = mh.anneal(g, "constant", [1.0], n, BIG)
+    for o, c in zip(oracles, sample):
+        assert o.anneal("constant", [1.0], n, BIG) == rates[c]
+        assert_state_equal(g, o, c)
+    s1 = g.entropy()
+    dcum = g.get_entropy() - cum0
+    assert np.allclose(s1 - s0, dcum, rtol=1e-9, atol=1e-6 * np.abs(dcum).max())
+    for c in range(0, chains, 13):
+        ka, kb = g.ka_kb(c)
+        lab, n_r = g.get_memberships(c), g.get_n_r(c)
+        assert (np.bincount(lab, minlength=ka + kb) == n_r).all() and n_r.min() >= 1
+        assert lab[:na].max() == ka - 1 and lab[na:].min() == ka and lab[na:].max() == ka + kb - 1
+        assert g.get_m_r(c).sum() == 2 * 10_000_000
+    ms, updates = g.last_sweep_timing()
+    assert updates == chains * n and ms > 0
+
+
 # ------------------------------------------------------------------ BASELINE configs[4]: per-GPU shape
 def test_config5_shape_properties():
     """N_a = N_b = 2e6, E = 5e7, Ka = Kb = 64 (the K > 32 variant of the production kernel, eta in HBM), 16 chains:
