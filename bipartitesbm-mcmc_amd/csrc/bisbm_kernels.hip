@@ -882,18 +882,28 @@ __global__ __launch_bounds__(kWave) void entropy_kernel(EntropyParams p) {
 // marginals: counts[v][block index within v's type] += #chains whose label of v is that block.
 // Thread = node; labels are read coalesced along the node axis of the chain-major array.
 // ------------------------------------------------------------------------------------------
+template <class LabelT, bool IN_LDS>
 __global__ __launch_bounds__(256) void marginals_kernel(MarginalParams p) {
-    extern __shared__ __align__(16) uint32_t hist[];  // 256 node rows x (kmax | 1) counters: one row per thread
+    extern __shared__ __align__(16) uint32_t hist[];  // IN_LDS: one row of (kmax | 1) counters per thread
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t stride = p.kmax | 1u;
-    uint32_t* row = hist + threadIdx.x * stride;
-    for (uint32_t j = 0; j < p.kmax; ++j) row[j] = 0;
-    if (v < p.n) {
+    const LabelT* labels = (const LabelT*)p.labels;
+    if constexpr (IN_LDS) {
+        const uint32_t stride = p.kmax | 1u;
+        uint32_t* row = hist + threadIdx.x * stride;
+        for (uint32_t j = 0; j < p.kmax; ++j) row[j] = 0;
+        if (v < p.n) {
+            const uint32_t base = v < p.na ? 0 : p.ka;
+            for (uint32_t c = 0; c < p.n_chains; ++c) row[(uint32_t)labels[(size_t)c * p.label_stride + v] - base] += 1;
+            uint32_t* out = p.counts + (size_t)v * p.kmax;
+            for (uint32_t j = 0; j < p.kmax; ++j)
+                if (row[j]) out[j] += row[j];
+        }
+    } else if (v < p.n) {
+        // many blocks (a row of counters per thread no longer fits the LDS): the thread owns row v of the histogram, so
+        // it can count straight into it
         const uint32_t base = v < p.na ? 0 : p.ka;
-        for (uint32_t c = 0; c < p.n_chains; ++c) row[(uint32_t)p.labels[(size_t)c * p.label_stride + v] - base] += 1;
         uint32_t* out = p.counts + (size_t)v * p.kmax;
-        for (uint32_t j = 0; j < p.kmax; ++j)
-            if (row[j]) out[j] += row[j];
+        for (uint32_t c = 0; c < p.n_chains; ++c) out[(uint32_t)labels[(size_t)c * p.label_stride + v] - base] += 1;
     }
 }
 
@@ -1256,9 +1266,23 @@ hipError_t launch_entropy(const EntropyParams& p, hipStream_t stream) {
 
 hipError_t launch_marginals(const MarginalParams& p, hipStream_t stream) {
     const size_t lds = sizeof(uint32_t) * 256 * (p.kmax | 1u);
-    hipError_t e = hipFuncSetAttribute((const void*)marginals_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const dim3 grid((p.n + 255) / 256), block(256);
+    if (lds > 160 * 1024) {  // more than ~159 blocks of a type: a row of counters per thread does not fit the LDS, count in HBM
+        if (p.wide)
+            hipLaunchKernelGGL((marginals_kernel<uint16_t, false>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((marginals_kernel<uint8_t, false>), grid, block, 0, stream, p);
+        return hipGetLastError();
+    }
+    if (p.wide) {
+        hipError_t e = hipFuncSetAttribute((const void*)marginals_kernel<uint16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((marginals_kernel<uint16_t, true>), grid, block, lds, stream, p);
+        return hipGetLastError();
+    }
+    hipError_t e = hipFuncSetAttribute((const void*)marginals_kernel<uint8_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(marginals_kernel, dim3((p.n + 255) / 256), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((marginals_kernel<uint8_t, true>), grid, block, lds, stream, p);
     return hipGetLastError();
 }
 

@@ -119,6 +119,7 @@ struct MarginalParams {
     const uint8_t* labels;
     size_t label_stride;
     uint32_t* counts;
+    uint32_t wide;  // two-byte labels (see SweepParams::wide)
 };
 
 // agg_split (blockmodel.cc:505-565): evaluation of `n_trials` random half-cuts of every block of one type, all chains

@@ -907,7 +907,6 @@ int bisbm_marginals_reset(bisbm_handle h) {
 int bisbm_marginals_accumulate(bisbm_handle h, uint32_t* device_counts) {
     if (!h) return BISBM_ERR_INVALID_ARG;
     if (!h->groups.empty()) return fail(h, BISBM_ERR_STATE, "the chains of this handle have different block counts: no common marginal histogram");
-    if (h->wide) return fail(h, BISBM_ERR_UNSUPPORTED, "marginal histograms are kept for at most 256 blocks (KA + KB = %u)", h->K);
     HIPCHK(h, hipSetDevice(h->device));
     if (!device_counts) {
         // (a histogram made before a merge / split changed max(KA, KB) has another row length: start afresh)
@@ -925,6 +924,7 @@ int bisbm_marginals_accumulate(bisbm_handle h, uint32_t* device_counts) {
     mp.n_chains = h->n_chains;
     mp.labels = h->d_labels;
     mp.label_stride = h->label_stride;
+    mp.wide = h->wide ? 1u : 0u;
     mp.counts = device_counts;
     HIPCHK(h, launch_marginals(mp, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

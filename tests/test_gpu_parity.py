@@ -340,6 +340,22 @@ def test_marginalize_driver_matches_oracle_samples():
         B.marginalize(g2, 0, 1, 1, device_counts=dev.data_ptr())  # a raw pointer is refused
 
 
+@pytest.mark.parametrize("ka,kb", [(170, 40), (200, 150)])
+def test_marginal_histogram_with_many_blocks(ka, kb):
+    """More than ~159 blocks of a type: a row of counters per thread no longer fits the LDS and the histogram is counted in
+    HBM -- with byte labels (170 + 40) and in wide mode (200 + 150, two-byte labels)."""
+    rowptr, col = cases.random_graph(17, 400, 300, 6000, ka, kb)
+    na, nb = 400, 300
+    g = gpu_model(rowptr, col, na, nb, ka, kb, 1.0, O.contiguous_labels(na, nb, ka, kb), n_chains=5, rng="philox", seed=9)
+    g.shuffle_bisbm()
+    B.MetropolisHasting().anneal(g, "constant", [1.0], 2 * (na + nb), BIG)
+    g.marginals_reset()
+    g.marginals_accumulate(None)
+    g.marginals_accumulate(None)
+    want = 2 * B.distributed.numpy_marginals(np.stack([g.get_memberships(c) for c in range(5)]), na, ka, kb)
+    assert (g.marginals_get() == want).all() and want.sum() == 2 * 5 * (na + nb)
+
+
 # ------------------------------------------------------------------ agglomerative merges (SURVEY 8 f2)
 def _merge_schedule(o, g, stages, mh, n):
     """mcmc_main.cc:379-396 / :425-444: one agg_merge per geospace stage, a greedy sweep (abrupt_cool, kwargs {0})
@@ -808,8 +824,8 @@ def test_cli_merge_nature_on_1000_nodes():
 
 def test_wide_mode_merges_down_into_byte_labels():
     """API level, both RNG modes, several chains: 150 + 150 blocks (wide) merged to 140 + 140 (still wide), swept, merged to
-    100 + 100 (byte labels from here), swept -- state equal to the oracle's after every call; what wide mode does not
-    serve (marginal histograms, splits) is refused with a message."""
+    100 + 100 (byte labels from here), swept -- state equal to the oracle's after every call; the marginal histogram is served there too,
+    splits are refused with a message."""
     rowptr, col = cases.random_graph(91, 300, 300, 5000, 150, 150)
     na = nb = 300
     n = na + nb
@@ -829,9 +845,11 @@ def test_wide_mode_merges_down_into_byte_labels():
             o.shuffle_bisbm()
             os_.append(o)
         with pytest.raises(RuntimeError, match="256 blocks"):
-            g.marginals_accumulate(None)
-        with pytest.raises(RuntimeError, match="256 blocks"):
             g.agg_merge(-1, 0, 5)
+        g.marginals_reset()  # (the histogram is counted in HBM when a row of counters per thread no longer fits the LDS)
+        g.marginals_accumulate(None)
+        want = B.distributed.numpy_marginals(np.stack([o.memberships() for o in os_]), na, 150, 150)
+        assert (g.marginals_get() == want).all()
         for (da, db), sched in (((10, 10), ("constant", [1.0])), ((40, 40), ("abrupt_cool", [0.0]))):
             g.agg_merge(da, db, 10)
             for o in os_:
