@@ -1,0 +1,141 @@
+"""Model-based random testing of the C ABI on the GPU (-m gpu): random call sequences -- set / shuffle / init / anneal under
+every schedule / two-argument merges and splits / one-argument merges (chains may end with different block counts) /
+entropy / marginals -- on random small graphs, both RNG modes, several chains, with the oracle as the model: after every call
+each chain's labels, block state, acceptance rate, sum dS and description length must equal its oracle run's."""
+import importlib
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+B = importlib.import_module("bipartitesbm-mcmc_amd")
+SYN = importlib.import_module("bipartitesbm-mcmc_amd.synthetic")
+BIG = 1 << 60
+
+
+def _check(g, os_, what):
+    ent, cum = g.entropy(), g.get_entropy()
+    ent, cum = np.atleast_1d(ent), np.atleast_1d(cum)
+    for c, o in enumerate(os_):
+        assert g.ka_kb(c) == (o.ka, o.kb), (what, c)
+        assert (g.get_memberships(c) == o.memberships()).all(), (what, c)
+        assert (g.get_m(c) == o.m()).all() and (g.get_m_r(c) == o.m_r()).all(), (what, c)
+        assert (g.get_n_r(c) == o.n_r()).all() and (g.get_eta_rk_(c) == o.eta()).all(), (what, c)
+        assert abs(ent[c] - o.entropy()) <= 1e-9 * max(1.0, abs(o.entropy())), (what, c)
+        assert abs(cum[c] - o.get_entropy()) <= 1e-9 * max(1.0, abs(o.get_entropy())), (what, c)
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_random_call_sequences(seed):
+    rng = np.random.default_rng(1000 + seed)
+    mode = "compat" if seed % 2 else "philox"
+    na, nb = int(rng.integers(20, 120)), int(rng.integers(20, 120))
+    n = na + nb
+    ne = int(rng.integers(2, 8) * n)
+    wide_start = seed % 6 == 5  # some sequences start above 256 blocks (two-byte labels) and merge their way down
+    if wide_start:
+        na, nb = int(rng.integers(140, 200)), int(rng.integers(140, 200))
+        n = na + nb
+        ka, kb = int(rng.integers(130, na)), int(rng.integers(130, nb))
+    else:
+        ka, kb = int(rng.integers(1, min(na, 40))), int(rng.integers(1, min(nb, 40)))
+    rowptr, col = cases.random_graph(int(rng.integers(1 << 30)), na, nb, ne, ka, kb, hubs=int(rng.integers(0, 3)),
+                                     isolated=int(rng.integers(0, 3)))
+    eps = float(rng.choice([1.0, 0.5, 0.001, 0.0, 3.0]))
+    chains = int(rng.integers(1, 5))
+    labels = O.contiguous_labels(na, nb, ka, kb)
+    s0, s1 = int(rng.integers(1 << 20)), int(rng.integers(1 << 20))
+    g = B.BlockModel(labels, SYN.types_vector(na, nb), ka + kb, ka, kb, eps, (rowptr, col), n_chains=chains, rng=mode, seed=s0, gen_seed=s1)
+    os_ = []
+    for c in range(chains):
+        o = O.OracleModel(rowptr, col, na, nb, ka, kb, eps, labels)
+        if mode == "compat":
+            o.seed_compat(s0 + c, s1 + c)
+        else:
+            o.seed_philox(s0, c)
+        os_.append(o)
+    mh = B.MetropolisHasting()
+    if rng.random() < 0.7:
+        g.shuffle_bisbm()
+        for o in os_:
+            o.shuffle_bisbm()
+    else:
+        g.init_bisbm()
+        for o in os_:
+            o.init_bisbm()
+    _check(g, os_, "start")
+    log = []
+    for step in range(int(rng.integers(6, 11))):
+        kas, kbs = [o.ka for o in os_], [o.kb for o in os_]
+        op = rng.choice(["anneal", "anneal", "anneal", "merge2", "merge1", "split", "shuffle", "set", "marginals"])
+        if op == "anneal":
+            sched, kw = [("constant", [float(rng.choice([1.0, 0.5, 2.0]))]), ("linear", [2.0, 1.5 / (3 * n)]),
+                         ("abrupt_cool", [float(rng.integers(0, 2 * n))]), ("exponential", [3.0, 0.999]),
+                         ("logarithmic", [1.0, 2.0])][int(rng.integers(5))]
+            dur = int(rng.integers(1, 4)) * n
+            await_ = BIG if rng.random() < 0.7 else int(rng.integers(n, 3 * n))
+            rg = np.atleast_1d(mh.anneal(g, sched, kw, dur, await_))
+            for c, o in enumerate(os_):
+                assert rg[c] == o.anneal(sched, kw, dur, await_), (log, sched, c)
+        elif op == "merge2":
+            da, db = int(rng.integers(0, max(1, min(kas) // 3 + 1))), int(rng.integers(0, max(1, min(kbs) // 3 + 1)))
+            if da >= min(kas) or db >= min(kbs) or da + db == 0:
+                continue
+            rcs = [o.agg_merge(da, db, 10) for o in os_]
+            if any(rcs):  # (the reference would recurse without end: the engine reports it)
+                with pytest.raises(B.BisbmError):
+                    g.agg_merge(da, db, 10)
+                return
+            g.agg_merge(da, db, 10)
+        elif op == "merge1":
+            d = int(rng.integers(1, max(2, min(a + b for a, b in zip(kas, kbs)) // 4 + 1)))
+            if any(d >= a + b - 2 for a, b in zip(kas, kbs)):
+                continue
+            rcs = [o.agg_merge_total(d, 10) for o in os_]
+            if any(rcs):
+                with pytest.raises(B.BisbmError):
+                    g.agg_merge(d, None, 10)
+                return
+            g.agg_merge(d, None, 10)
+        elif op == "split":
+            if max(a + b for a, b in zip(kas, kbs)) + 1 > 256 or len({(a, b) for a, b in zip(kas, kbs)}) > 1 and False:
+                continue
+            type_b = bool(rng.integers(2))
+            rcs = [o.agg_merge(0 if type_b else -1, -1 if type_b else 0, 7) for o in os_]
+            if any(rcs):  # no block of the type has two nodes
+                with pytest.raises(B.BisbmError):
+                    g.agg_merge(0 if type_b else -1, -1 if type_b else 0, 7)
+                return
+            g.agg_merge(0 if type_b else -1, -1 if type_b else 0, 7)
+        elif op == "shuffle":
+            g.shuffle_bisbm()
+            for o in os_:
+                o.shuffle_bisbm()
+        elif op == "set":
+            c = int(rng.integers(chains))
+            lab = os_[int(rng.integers(chains))].memberships()
+            if lab[:na].max() >= os_[c].ka or lab[na:].max() >= os_[c].ka + os_[c].kb or lab[na:].min() < os_[c].ka:
+                continue  # (another chain's labels need not be blocks of this chain's shape)
+            g.set_memberships(lab, chain=c)
+            g.init_bisbm()
+            os_[c].set_memberships(lab)
+            for o in os_:
+                o.init_bisbm()
+        elif op == "marginals":
+            if len({(a, b) for a, b in zip(kas, kbs)}) > 1:
+                with pytest.raises(B.BisbmError):
+                    g.marginals_reset()
+                continue
+            g.marginals_reset()
+            g.marginals_accumulate(None)
+            want = B.distributed.numpy_marginals(np.stack([o.memberships() for o in os_]), na, kas[0], kbs[0])
+            assert (g.marginals_get() == want).all(), log
+            continue
+        log.append(op)
+        _check(g, os_, (seed, mode, log))
+    print("seed %d %s %d+%d nodes, start %d+%d blocks, %d chains, eps %g: %s -> shapes %s"
+          % (seed, mode, na, nb, ka, kb, chains, eps, " ".join(log), sorted({(o.ka, o.kb) for o in os_})))
