@@ -329,6 +329,13 @@ int each_group(bisbm_engine* h, F f) {
     }
     return BISBM_OK;
 }
+// container handles: do all groups have one shape (again)?  If so the handle's own ka / kb / K follow it.
+bool common_shape(bisbm_engine* h) {
+    for (bisbm_engine* g : h->groups)
+        if (g->ka != h->groups[0]->ka || g->kb != h->groups[0]->kb) return false;
+    h->ka = h->groups[0]->ka, h->kb = h->groups[0]->kb, h->K = h->ka + h->kb;
+    return true;
+}
 // ... and gather one value per chain from the groups into the handle's chain order
 template <class T, class F>
 int gather_groups(bisbm_engine* h, T* out, F f) {
@@ -886,7 +893,8 @@ int bisbm_entropy(bisbm_handle h, double* out) {
 
 int bisbm_marginals_reset(bisbm_handle h) {
     if (!h) return BISBM_ERR_INVALID_ARG;
-    if (!h->groups.empty()) return fail(h, BISBM_ERR_STATE, "the chains of this handle have different block counts: no common marginal histogram");
+    if (!h->groups.empty() && !common_shape(h))
+        return fail(h, BISBM_ERR_STATE, "the chains of this handle have different block counts: no common marginal histogram");
     HIPCHK(h, hipSetDevice(h->device));
     const uint32_t kmax = std::max(h->ka, h->kb);
     const size_t cnt = (size_t)h->n * kmax;
@@ -906,7 +914,8 @@ int bisbm_marginals_reset(bisbm_handle h) {
 
 int bisbm_marginals_accumulate(bisbm_handle h, uint32_t* device_counts) {
     if (!h) return BISBM_ERR_INVALID_ARG;
-    if (!h->groups.empty()) return fail(h, BISBM_ERR_STATE, "the chains of this handle have different block counts: no common marginal histogram");
+    if (!h->groups.empty() && !common_shape(h))
+        return fail(h, BISBM_ERR_STATE, "the chains of this handle have different block counts: no common marginal histogram");
     HIPCHK(h, hipSetDevice(h->device));
     if (!device_counts) {
         // (a histogram made before a merge / split changed max(KA, KB) has another row length: start afresh)
@@ -916,6 +925,8 @@ int bisbm_marginals_accumulate(bisbm_handle h, uint32_t* device_counts) {
         }
         device_counts = h->d_counts;
     }
+    if (!h->groups.empty())  // groups that have come to one shape again: every group adds its chains to the same histogram
+        return each_group(h, [&](bisbm_engine* g) { return bisbm_marginals_accumulate(g, device_counts); });
     MarginalParams mp{};
     mp.n = (uint32_t)h->n;
     mp.na = (uint32_t)h->na;
@@ -934,6 +945,8 @@ int bisbm_marginals_accumulate(bisbm_handle h, uint32_t* device_counts) {
 int bisbm_marginals_get(bisbm_handle h, uint32_t* counts_out) {
     if (!h) return BISBM_ERR_INVALID_ARG;
     if (!counts_out) return fail(h, BISBM_ERR_INVALID_ARG, "counts_out is NULL");
+    if (!h->groups.empty() && !common_shape(h))
+        return fail(h, BISBM_ERR_STATE, "the chains of this handle have different block counts: no common marginal histogram");
     if (!h->d_counts) return fail(h, BISBM_ERR_STATE, "no internal marginal buffer yet");
     if (h->counts_cols != std::max(h->ka, h->kb))
         return fail(h, BISBM_ERR_STATE, "the block counts changed since the histogram was made (%u columns then, %u now)", h->counts_cols,
@@ -946,7 +959,7 @@ int bisbm_marginals_get(bisbm_handle h, uint32_t* counts_out) {
 
 int bisbm_get_ka_kb(bisbm_handle h, uint32_t* ka, uint32_t* kb) {
     if (!h) return BISBM_ERR_INVALID_ARG;
-    if (!h->groups.empty())
+    if (!h->groups.empty() && !common_shape(h))
         return fail(h, BISBM_ERR_STATE, "the chains of this handle have different block counts: ask per chain (bisbm_get_ka_kb_chain)");
     if (ka) *ka = h->ka;
     if (kb) *kb = h->kb;

@@ -149,12 +149,12 @@ int bisbm_agg_merge(bisbm_handle h, int diff_a, int diff_b, int nm);
  * each chain's own proposals, so the chains of a handle may end with different (Ka,Kb).  The handle then keeps them
  * grouped by shape internally (kernels are launched for one shape: one launch per group from then on); every call
  * keeps working per chain -- anneal, memberships, block state (array sizes follow bisbm_get_ka_kb_chain), sum dS,
- * entropy, further merges of either overload -- except the ones that need one common shape: bisbm_get_ka_kb and the
- * marginal histogram return BISBM_ERR_STATE.  diff < 0 is BISBM_ERR_INVALID_ARG (this overload has no split branch). */
+ * entropy, further merges of either overload -- except that the calls which need one common shape (bisbm_get_ka_kb, the
+ * marginal histogram) return BISBM_ERR_STATE while the chains' shapes differ (later merges may bring them together again).  diff < 0 is BISBM_ERR_INVALID_ARG (this overload has no split branch). */
 int bisbm_agg_merge_total(bisbm_handle h, int diff, int nm);
 
 /* Shape queries (get_KA/get_KB blockmodel.cc:103-105, get_num_edges :81).  bisbm_get_ka_kb: the block counts all chains
- * share (BISBM_ERR_STATE once a one-argument agg_merge left them with different ones); bisbm_get_ka_kb_chain: one chain's. */
+ * share (BISBM_ERR_STATE while a one-argument agg_merge has left them with different ones); bisbm_get_ka_kb_chain: one chain's. */
 int bisbm_get_ka_kb(bisbm_handle h, uint32_t *ka, uint32_t *kb);
 int bisbm_get_ka_kb_chain(bisbm_handle h, uint32_t chain, uint32_t *ka, uint32_t *kb);
 int bisbm_get_sizes(bisbm_handle h, uint64_t *n, uint64_t *num_edges, uint32_t *max_degree,
