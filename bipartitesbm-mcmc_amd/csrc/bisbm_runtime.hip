@@ -1814,6 +1814,9 @@ int merge_total_grouped(bisbm_engine* h, int diff, int nm) {
         remap_groups(h);
         return BISBM_OK;
     }
+    for (bisbm_engine* g : h->groups)  // (all or nothing, as in bisbm_agg_merge)
+        if (diff > (int)g->ka + (int)g->kb - 2)
+            return fail(h, BISBM_ERR_STATE, "agg_merge(%d): a chain of this handle has %u + %u blocks", diff, g->ka, g->kb);
     std::vector<bisbm_engine*> next;
     int rc_all = BISBM_OK;
     for (bisbm_engine* g : h->groups) {
@@ -1844,6 +1847,9 @@ int merge_total_grouped(bisbm_engine* h, int diff, int nm) {
 int bisbm_agg_merge(bisbm_handle h, int diff_a, int diff_b, int nm) {
     if (!h) return BISBM_ERR_INVALID_ARG;
     if (!h->groups.empty()) {  // the same change of counts in every group: each keeps one shape
+        for (bisbm_engine* g : h->groups)  // (all or nothing: a request no chain of some group can meet is refused before any group changes)
+            if (diff_a >= (int)g->ka || diff_b >= (int)g->kb)
+                return fail(h, BISBM_ERR_STATE, "agg_merge(%d, %d): a chain of this handle has %u + %u blocks", diff_a, diff_b, g->ka, g->kb);
         for (bisbm_engine* g : h->groups) {
             const int rc = run_merges(g, 0, diff_a, diff_b, nm);
             if (rc) {

@@ -78,7 +78,27 @@ def test_random_call_sequences(seed):
     log = []
     for step in range(int(rng.integers(6, 11))):
         kas, kbs = [o.ka for o in os_], [o.kb for o in os_]
-        op = rng.choice(["anneal", "anneal", "anneal", "merge2", "merge1", "split", "shuffle", "set", "marginals"])
+        op = rng.choice(["anneal", "anneal", "anneal", "merge2", "merge1", "split", "shuffle", "set", "marginals", "bad"])
+        if op == "bad":  # a call that must fail and leave everything as it was
+            import ctypes as C
+            kind = int(rng.integers(5))
+            with pytest.raises(B.BisbmError):
+                if kind == 0:
+                    lab = os_[0].memberships()
+                    lab[int(rng.integers(na))] = os_[0].ka  # a type-b block for a type-a node
+                    g.set_memberships(lab, chain=0)
+                elif kind == 1:
+                    g.get_memberships(chains)  # no such chain
+                elif kind == 2:
+                    g._check(g._L.bisbm_anneal(g._h, 9, (C.c_float * 2)(1.0, 0.0), n, BIG, None))  # no such schedule
+                elif kind == 3:
+                    g.agg_merge(-1, None, 5)  # the one-argument overload has no split branch
+                else:
+                    g.agg_merge(min(kas), 0, 5) if min(kas) > 0 else g.get_memberships(chains)  # every type-a block merged away
+            if kind == 0:
+                g.init_bisbm()  # (set_memberships validates before it touches anything; the state stays built)
+            _check(g, os_, (seed, mode, log, "bad", kind))
+            continue
         if op == "anneal":
             sched, kw = [("constant", [float(rng.choice([1.0, 0.5, 2.0]))]), ("linear", [2.0, 1.5 / (3 * n)]),
                          ("abrupt_cool", [float(rng.integers(0, 2 * n))]), ("exponential", [3.0, 0.999]),
