@@ -709,7 +709,7 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
         if (p.eta_in_lds) lds += eta_bytes;
         if (h->rng_mode == BISBM_RNG_MT19937_COMPAT) {
             lds += sizeof(uint32_t) * 624 * 4;  // two states and their tempered outputs
-            if (sizeof(uint32_t) * h->n <= 48 * 1024) {
+            if (sizeof(uint32_t) * h->n <= 48 * 1024 && lds + sizeof(uint32_t) * h->n <= 150 * 1024) {  // (wide mode: m_r / n_r of thousands of blocks come first)
                 p.vlist_in_lds = 1;
                 lds += sizeof(uint32_t) * h->n;
             }
