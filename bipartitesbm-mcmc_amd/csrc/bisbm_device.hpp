@@ -113,6 +113,26 @@ __device__ __forceinline__ double butterfly_rows32(double x) {
     return x;
 }
 
+// Four 16-leaf butterflies at once, one per row of the wave: the first four levels of butterfly_sum.  Every lane of a row ends
+// up with its row's sum (levels 1, 2 are quad permutes, then the two mirror permutes pair whole quads / octets).  Same bits
+// as butterfly_sum over 64 leaves whose leaves 16..63 are +0.0: the last two levels add x + 0.0.
+__device__ __forceinline__ double butterfly_rows16(double x) {
+    x = x + dpp_f64<kDppXor1>(x);
+    x = x + dpp_f64<kDppXor2>(x);
+    x = x + dpp_f64<kDppHalfMirror>(x);
+    x = x + dpp_f64<kDppMirror>(x);
+    return x;
+}
+
+// inclusive prefix sum inside every 16-lane row (row_shr never leaves its row)
+__device__ __forceinline__ int row_inclusive_scan16(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);  // row_shr:8
+    return x;
+}
+
 // inclusive prefix sum of int32 over the wave: Kogge-Stone inside rows (row_shr), then the row
 // totals are carried with row_bcast15 / row_bcast31
 __device__ __forceinline__ int wave_inclusive_scan(int x) {

@@ -67,7 +67,8 @@ struct SweepParams {
     // the workgroups keep their stepping waves on different SIMDs; NULL: wave `fixed_stepping_wave` (0 or 1) steps
     uint32_t* simd_claims;
     uint32_t fixed_stepping_wave;
-    // production kernel, K <= 32 and constant T: evaluate two consecutive steps per pass (0: one step per pass)
+    // production kernel: 0 = one step per pass; 1 = two consecutive steps per pass where both block counts are <= 32;
+    // 2 = also four per pass where both are <= 16
     uint32_t pair_steps;
     // wide mode (KA + KB > 256; generic kernel only): `labels` holds two-byte labels (label_stride counts labels, not
     // bytes), and the a x b quadrant of m is read and updated in HBM

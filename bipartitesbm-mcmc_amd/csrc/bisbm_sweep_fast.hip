@@ -111,8 +111,9 @@ constexpr uint32_t kRowCap = 255;     // longest row the feeder walks (a k_v cou
     double name = (value);     \
     __asm__ volatile("" : "+v"(name))
 
-// EL: eta in LDS.  CT: constant schedule.  K32: both block counts <= 32 (five-level scans and sums).
-template <bool EL, bool CT, bool K32>
+// EL: eta in LDS.  CT: constant schedule.  K32: both block counts <= 32 (five-level scans and sums).  K16 (with K32): both
+// block counts <= 16: four steps per pass in the four 16-lane rows of the wave (step_quad).
+template <bool EL, bool CT, bool K32, bool K16>
 __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p) {
     extern __shared__ __align__(16) uint32_t lds32[];
     const uint32_t chain = blockIdx.x;
@@ -190,8 +191,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     // critical path, so it issues first whenever both have an instruction ready.
     if (is_main) __builtin_amdgcn_s_setprio(3);
     // lane <-> block: m_r / n_r of block i sit in lane i; the K <= 32 variants keep a second copy in lane 32 + i, so that
-    // the upper half of the wave can run a step of its own (step_pair below)
-    const uint32_t lb = K32 ? (lane & 31u) : lane;
+    // the upper half of the wave can run a step of its own (step_pair below); the K <= 16 variants keep four copies (step_quad)
+    const uint32_t lb = K16 ? (lane & 15u) : K32 ? (lane & 31u) : lane;
     int mrA = lb < ka ? mr_g[lb] : 0, nrA = lb < ka ? nr_g[lb] : 0;
     int mrB = lb < kb ? mr_g[ka + lb] : 0, nrB = lb < kb ? nr_g[ka + lb] : 0;
     __syncthreads();
@@ -215,8 +216,9 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     // the early-stop bookkeeping can only ever fire below T = 1, and only if steps_await can be reached within the call
     // (the counter starts at 0 and gains at most 1 per step) -- a scalar word, not a lane mask: one s_cmp to test
     // two steps per pass (step_pair): K <= 32 (a constant schedule at T = 0 takes the general step anyway);
-    // p.pair_steps == 0 switches it off (A/B runs, tests)
+    // p.pair_steps == 0 switches it off (A/B runs, tests); 2: four steps per pass where both block counts are <= 16
     const bool pair_mode = (uint32_t)__builtin_amdgcn_readfirstlane((K32 && (!CT || T_const > 0.) && p.pair_steps != 0) ? 1 : 0) != 0u;
+    const bool quad_mode = (uint32_t)__builtin_amdgcn_readfirstlane((K16 && (!CT || T_const > 0.) && p.pair_steps > 1u) ? 1 : 0) != 0u;
     const uint32_t track_min =
         (uint32_t)__builtin_amdgcn_readfirstlane(((!CT || T_const < 1.) && p.steps_await <= p.duration) ? 1 : 0);
     // constants of the hot step (log_q closed form, accept filter)
@@ -266,6 +268,11 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
             };
             const double sign_tail = lb >= 8 ? 0. : ((lb < 2 || lb >= 6) ? -1. : 1.);
             const double sign_q = lb >= 4 ? 0. : (lb < 2 ? -1. : 1.);
+            // the one-step evaluations (step_general, step) sum lanes 0..31 or 0..63 as ONE step: only its first row carries
+            // the scalar terms (with four copies per wave, K <= 16, lanes 16..23 would add them a second time)
+            // (the other variants: the same registers as sign_tail / sign_q -- their one-step sums never reach a second copy)
+            const double sign_tail1 = K16 ? (lane < 16u ? sign_tail : 0.) : sign_tail;
+            const double sign_q1 = K16 ? (lane < 16u ? sign_q : 0.) : sign_q;
             const int eoff_l = (lane & 7u) < 6 ? 1 : ((lane & 1u) ? 2 : 0);       // eta_r+1, eta_s+1, eta_r, eta_s+2
             const int dq_l = (lane & 2u) ? ((lane & 1u) ? 1 : -1) : 0;            // n_r - 1, n_s + 1 in lanes 2,3 (mod 4)
             const int dsgn_l = dq_l;                                              // -deg, +deg in the same lanes
@@ -511,8 +518,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     // (sign_tail: -lg(m0r+1) -lg(m0s+1) +lg(m1r+1) +lg(m1s+1) +lg(eta_r+1) +lg(eta_s+1) -lg(eta_r)
                     // -lg(eta_s+2), zero from lane 8 on; sign_q: -,-,+,+, zero from lane 4 on.  x * (+-1) is exact and
                     // idle lanes add a zero: the table values are finite)
-                    d = d + tail_lg * sign_tail;
-                    d = d + lq * sign_q;
+                    d = d + tail_lg * sign_tail1;
+                    d = d + lq * sign_q1;
                     double dS = k_oth <= 32u ? butterfly_sum_low32(d) : butterfly_sum(d);
                     // accept (:47-61): T == 0: dS < 0;  else u < exp(-dS/T) accu1/accu0
                     bool accept;
@@ -667,8 +674,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     }
                     FSTAMP_STEP(5);
                     double d = (L1 + L2) - (L3 + L4);
-                    d = d + tail_lg * sign_tail;  // scalar terms folded into leaves 0..7 / 0..3, see step_general
-                    d = d + lq * sign_q;
+                    d = d + tail_lg * sign_tail1;  // scalar terms folded into leaves 0..7 / 0..3, see step_general
+                    d = d + lq * sign_q1;
                     const double dS = K32 ? butterfly_sum_low32(d) : butterfly_sum(d);
                     FSTAMP_STEP(6);
                     if (!CT && T == 0.) {  // the greedy tail of a cooling schedule (:49-50): dS < 0 decides
@@ -902,6 +909,199 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     return 1u + stands;
                 };
 
+                // ---- four steps per pass (both block counts <= 16) ----
+                // The same idea one level further: row g of the wave (lanes 16 g .. 16 g + 15, one lane per block) evaluates
+                // step q + g against the state before step q.  Steps are committed in order as long as each one's
+                // evaluation stands, i.e. no step committed before it in this pass moved its node AND touched what it
+                // read (the rule of step_pair, applied to every earlier mover: their writes touch disjoint rows, so the
+                // conditions compose); the first step that does not stand opens the next pass.  The six pairwise tests
+                // are evaluated lane-parallel (lane 4 i + j: steps i and j) and arrive as one 16-bit word.
+                const uint32_t row = lane >> 4;
+                auto step_quad = [&](auto tm, uint32_t q, uint32_t nst) -> uint32_t {  // nst: steps of this pass that exist (1..4)
+                    constexpr bool TM = decltype(tm)::value;
+                    const uint32_t qs = q + min(row, nst - 1u);  // (rows past nst repeat the last step; their results are ignored)
+                    const int sel = (int)(qs << 2);
+                    const uint32_t prop = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)prop_l);
+                    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)v_l);
+                    const uint32_t pack = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)pack_l);
+                    const double u_acc = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(ud_acc)),
+                                                          __builtin_amdgcn_ds_bpermute(sel, __double2loint(ud_acc)));
+                    const uint32_t deg = pack & 255u, r_loc = (pack >> 8) & 63u, t_loc = pack >> 16;
+                    const int k = (int)hist8_cur[qs * kHistStride + lb];
+                    const uint32_t a_rt = mq_at(r_loc, lb);
+                    const int32_t m_rt_raw = mq[a_rt];
+                    const int w_piv = mq[mq_at(lb, t_loc)];
+                    const int nn_r = __builtin_amdgcn_ds_bpermute((int)(r_loc << 2), nr_own);
+                    const int32_t kmask = (0 - k) >> 31;
+                    const int32_t m_rt = m_rt_raw & kmask;
+                    const uint32_t kk = (uint32_t)k;
+                    const double L1 = tab_at(tab.lg, (uint32_t)(m_rt + 1));
+                    const double L3 = tab_at(tab.lg, (uint32_t)(m_rt + 1) - kk);
+                    __asm__ volatile("" ::: "memory");
+                    // inverse CDF per row (:627-628): the row_shr scan does not leave its 16 lanes
+                    const int scan = row_inclusive_scan16(w_piv);
+                    const unsigned long long hit = __builtin_amdgcn_ballot_w64((uint32_t)scan > prop);
+                    const uint32_t field = (uint32_t)(hit >> (row << 4)) & 0xffffu;
+                    const uint32_t s_loc = min((uint32_t)__builtin_ctz(field | 0x10000u), last_own);
+                    const bool valid = row < nst;
+                    const bool self = s_loc == r_loc;
+                    const bool live = nn_r != 1;  // (:467-471: a block is never emptied)
+                    const bool warm = CT ? true : (((zeroT_mask >> qs) & 1ull) == 0ull);  // T = 0: r == s is not accepted (:49-50)
+                    constexpr unsigned long long kRowRep = 0x8000800080008000ull;  // one lane per row (its last)
+                    const unsigned long long b_can = __builtin_amdgcn_ballot_w64(valid && live && !self) & kRowRep;
+                    const unsigned long long b_selfok = __builtin_amdgcn_ballot_w64(valid && live && self && warm) & kRowRep;
+                    if (b_can == 0ull) {  // every step of the pass is an r == s (or a vetoed one): nothing changes (:109-112)
+                        acc_chunk += (uint32_t)__builtin_popcountll(b_selfok);
+                        return nst;
+                    }
+                    // pairwise: would step i, if it moves its node, touch what step j read?  (lane 4 i + j, any row)
+                    uint32_t clash_bits;
+                    {
+                        const int li = (int)(((lane >> 2) & 3u) << 6), lj = (int)((lane & 3u) << 6);  // lane 16 i, lane 16 j
+                        const uint32_t r_i = (uint32_t)__builtin_amdgcn_ds_bpermute(li, (int)r_loc);
+                        const uint32_t s_i = (uint32_t)__builtin_amdgcn_ds_bpermute(li, (int)s_loc);
+                        const uint32_t r_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)r_loc);
+                        const uint32_t s_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)s_loc);
+                        const uint32_t t_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)t_loc);
+                        const uint32_t k_i_tj = (uint32_t)__builtin_amdgcn_ds_bpermute(li + (int)(t_j << 2), (int)kk);  // k of step i at block t_j
+                        const uint32_t set_i = (1u << r_i) | (1u << s_i), set_j = (1u << r_j) | (1u << s_j);
+                        const uint32_t lo = min(r_i, s_i), hi = max(r_i, s_i);
+                        const uint32_t between = ((1u << hi) - 1u) & ~((2u << lo) - 1u);  // blocks strictly between r_i and s_i
+                        const bool clash = (set_i & set_j) != 0u || (((between >> s_j) & 1u) != 0u && k_i_tj != 0u);
+                        clash_bits = (uint32_t)__builtin_amdgcn_ballot_w64(clash) & 0xffffu;  // bit 4 i + j
+                    }
+                    const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
+                    const uint32_t a_st = mq_at(s_loc, lb);
+                    const int32_t m_st_raw = mq[a_st];
+                    const uint32_t e_idx = (own_base + idx_l) * D + deg;
+                    const int ee = (int)eta_rd(e_idx);
+                    const int mm = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), mr_own);
+                    const int nn = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), nr_own);
+                    const int32_t m_st = m_st_raw & kmask;
+                    const int ideg = (int)deg;
+                    const int qn = mm + __mul24(ideg, dsgn_l);        // m0r, m0s, m0r - deg, m0s + deg
+                    const uint32_t tail_idx = (uint32_t)((qn ^ ((qn ^ ee) & eta_mask_l)) + toff_l);
+                    const int qk = nn + dq_l;
+                    const double tail_lg = tab_at(tab.lg, tail_idx);
+                    const double logn = tab_at(tab.logtab, (uint32_t)qn);
+                    const double L2 = tab_at(tab.lg, (uint32_t)(m_st + 1));
+                    const double L4 = tab_at(tab.lg, (uint32_t)(m_st + 1) + kk);
+                    const double a0 = k * (m_st + eps) * inv_oth;
+                    const double a1 = k * (m_rt - k + eps) * inv_oth;
+                    const double accu0 = butterfly_rows16(a0);  // every lane of a row: the row's sum
+                    const double accu1 = butterfly_rows16(a1);
+                    double lq;
+                    {
+                        const int qk2 = qk < qn ? qk : qn;
+                        const double nd = (double)qn, kd = (double)qk2;
+                        const double k2 = kd * kd;
+                        const bool direct = qn > kQNmax && k2 > c_576 * nd;
+                        if (__builtin_amdgcn_ballot_w64(qn > kQNmax) == 0) {
+                            lq = log_q_table(tab, qn, qk2);  // small graphs: every argument inside the table (int_part.hh:27-37)
+                        } else if (__builtin_amdgcn_ballot_w64(!direct) == 0) {
+                            double sq, rr;
+                            sqrt_rsqrt(nd, sq, rr);
+                            lq = log_q_closed(kd, sq, rr, logn, lqc);
+                        } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= c_169 * nd)) == 0) {
+                            double sq, rr;
+                            sqrt_rsqrt(nd, sq, rr);
+                            lq = log_q_closed2(kd, sq, rr, logn, lqc);
+                        } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= ldexp(nd, 6))) == 0) {
+                            double sq, rr;
+                            sqrt_rsqrt(nd, sq, rr);
+                            const double lq_mid = log_q_mid(kd, sq, rr, logn, lqc);
+                            const double lq_far = log_q_closed(kd, sq, rr, logn, lqc);
+                            lq = direct ? lq_far : lq_mid;
+                        } else {
+                            lq = log_q<true>(tab, qn, qk, logn);
+                        }
+                    }
+                    double d = (L1 + L2) - (L3 + L4);
+                    d = d + tail_lg * sign_tail;
+                    d = d + lq * sign_q;
+                    const double dS = butterfly_rows16(d);
+                    // accept (:47-61), per row
+                    double invT = invT_const;
+                    if (!CT) invT = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(invT_l)),
+                                                     __builtin_amdgcn_ds_bpermute(sel, __double2loint(invT_l)));
+                    const double z = -dS * invT;
+                    const double est = accu1 * exp2_filter(z * c_l2e);
+                    const double lhs = u_acc * accu0;
+                    unsigned long long b_acc = __builtin_amdgcn_ballot_w64(warm ? lhs < est : dS < 0.);  // T = 0: dS < 0 decides (:49-50)
+                    const unsigned long long b_far = __builtin_amdgcn_ballot_w64(!warm || fabs(lhs - est) > c_tol * est);
+                    if (__builtin_expect((~b_far & b_can) != 0ull, 0)) {  // a verdict too close to call
+                        const unsigned long long exact = __builtin_amdgcn_ballot_w64(lhs < accu1 * exp(z));
+                        b_acc = (b_acc & b_far) | (exact & ~b_far);
+                    }
+                    // verdicts, in step order: bits 15 / 31 / 47 / 63 -> bits 0..3
+                    auto rows4 = [](unsigned long long b) -> uint32_t {
+                        const unsigned long long x = b >> 15;
+                        return (uint32_t)(x | (x >> 15) | (x >> 30) | (x >> 45)) & 0xfu;
+                    };
+                    const uint32_t can4 = rows4(b_can), mv4 = can4 & rows4(b_acc & kRowRep), selfok4 = rows4(b_selfok);
+                    // commit_j: steps 0..j all stand.  moved bits of committed steps only.
+                    uint32_t moved = mv4 & 1u, commit = 1u;
+                    {
+                        const uint32_t c01 = (clash_bits >> 1) & 1u, c02 = (clash_bits >> 2) & 1u, c03 = (clash_bits >> 3) & 1u;
+                        const uint32_t c12 = (clash_bits >> 6) & 1u, c13 = (clash_bits >> 7) & 1u, c23 = (clash_bits >> 11) & 1u;
+                        const uint32_t m0 = moved & 1u;
+                        const uint32_t k1 = sflag(nst - 1u) & ((m0 & c01) ^ 1u);  // (nst >= 2)
+                        const uint32_t m1 = k1 & (mv4 >> 1) & 1u;
+                        const uint32_t k2 = k1 & (nst > 2u ? 1u : 0u) & ((m0 & c02) ^ 1u) & ((m1 & c12) ^ 1u);
+                        const uint32_t m2 = k2 & (mv4 >> 2) & 1u;
+                        const uint32_t k3 = k2 & (nst > 3u ? 1u : 0u) & ((m0 & c03) ^ 1u) & ((m1 & c13) ^ 1u) & ((m2 & c23) ^ 1u);
+                        const uint32_t m3 = k3 & (mv4 >> 3) & 1u;
+                        commit = 1u | (k1 << 1) | (k2 << 2) | (k3 << 3);
+                        moved = m0 | (m1 << 1) | (m2 << 2) | (m3 << 3);
+                    }
+                    acc_chunk += (uint32_t)__builtin_popcount(moved | (commit & selfok4));
+                    if (moved != 0u) {
+                        // ---- apply_mcmc_moves, blockmodel.cc:461-503, for the steps that move: their rows of m differ ----
+                        unsigned long long movers = 0ull;
+                        if (moved & 1u) movers |= 0x000000000000ffffull;
+                        if (moved & 2u) movers |= 0x00000000ffff0000ull;
+                        if (moved & 4u) movers |= 0x0000ffff00000000ull;
+                        if (moved & 8u) movers |= 0xffff000000000000ull;
+                        wfence();
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & lanes_koth)) {  // k == 0: rewrites the same values
+                            mq[a_rt] = m_rt_raw - k;
+                            mq[a_st] = m_st_raw + k;
+                        }
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0030003000300030ull))  // lanes 4, 5 of a row: eta_r - 1, eta_s + 1
+                            eta_wr(e_idx, (uint32_t)(ee + ((int)(lb & 1u) * 2 - 1)));
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0001000100010001ull)) labels[v] = (uint8_t)(own_base + s_loc);
+                        // the register copies of m_r / n_r, sum dS (:500) and the early-stop bookkeeping, in step order
+#pragma unroll
+                        for (uint32_t g = 0; g < 4u; ++g) {
+                            if ((moved >> g) & 1u) {
+                                const uint32_t rg = readlane(r_loc, 16u * g), sg = readlane(s_loc, 16u * g), dg = readlane(deg, 16u * g);
+                                const int dl = (int)min(lb ^ rg, 1u) - (int)min(lb ^ sg, 1u);  // +1 on lane s, -1 on lane r
+                                mr_own += __mul24((int)dg, dl);
+                                nr_own += dl;
+                                cum_l0 += readlane(dS, 16u * g + 15u);
+                                if constexpr (TM) new_minimum(q + g);
+                            }
+                        }
+                        wfence();
+                    }
+                    return (uint32_t)__builtin_popcount(commit);
+                };
+                auto quad_loop = [&](auto tm) {
+                    const unsigned long long gen_mask = __builtin_amdgcn_ballot_w64((int32_t)prop_l < 0);
+                    uint32_t q = 0;
+                    acc_chunk = 0;
+                    while (q < cnt) {
+                        const uint32_t four = (uint32_t)(gen_mask >> q) & 0xfu;
+                        if (__builtin_expect((four & 1u) != 0u, 0)) {
+                            step_general(q, CT ? T_const : readlane(T_l, q));
+                            q += 1u;
+                        } else {  // the steps up to the next one that needs the general path, or to the end of the chunk
+                            const uint32_t nst = min(min((uint32_t)__builtin_ctz(four | 0x10u), 4u), cnt - q);
+                            q += step_quad(tm, q, nst);
+                        }
+                    }
+                    acc_l0 += (unsigned long long)acc_chunk;
+                };
                 // steps that need the general path (bit 31 of prop_l) go one at a time
                 auto pair_loop = [&](auto tm) {
                     const unsigned long long gen_mask = __builtin_amdgcn_ballot_w64((int32_t)prop_l < 0);
@@ -918,7 +1118,12 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     }
                     acc_l0 += (unsigned long long)acc_chunk;
                 };
-                if (K32 && pair_mode) {
+                if (K16 && quad_mode) {
+                    if (track_min != 0u)
+                        quad_loop(std::true_type{});
+                    else
+                        quad_loop(std::false_type{});
+                } else if (K32 && pair_mode) {
                     if (track_min != 0u)
                         pair_loop(std::true_type{});
                     else
@@ -1007,19 +1212,20 @@ size_t sweep_fast_lds_bytes(uint32_t ka, uint32_t kb, uint32_t maxdeg, bool eta_
     return ((dwords > reach ? dwords : reach) * 4 + 15) & ~(size_t)15;
 }
 
-template <bool EL, bool CT, bool K32>
+template <bool EL, bool CT, bool K32, bool K16>
 static hipError_t launch_fast_variant3(const SweepParams& p, size_t lds_bytes, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)sweep_fast_kernel<EL, CT, K32>,
+    hipError_t e = hipFuncSetAttribute((const void*)sweep_fast_kernel<EL, CT, K32, K16>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((sweep_fast_kernel<EL, CT, K32>), dim3(p.n_chains), dim3(2 * kWave), lds_bytes, stream, p);
+    hipLaunchKernelGGL((sweep_fast_kernel<EL, CT, K32, K16>), dim3(p.n_chains), dim3(2 * kWave), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
 template <bool EL, bool CT>
 static hipError_t launch_fast_variant(const SweepParams& p, size_t lds_bytes, hipStream_t stream) {
-    return (p.ka <= 32u && p.kb <= 32u) ? launch_fast_variant3<EL, CT, true>(p, lds_bytes, stream)
-                                        : launch_fast_variant3<EL, CT, false>(p, lds_bytes, stream);
+    if (p.ka <= 16u && p.kb <= 16u && p.pair_steps > 1u) return launch_fast_variant3<EL, CT, true, true>(p, lds_bytes, stream);
+    return (p.ka <= 32u && p.kb <= 32u) ? launch_fast_variant3<EL, CT, true, false>(p, lds_bytes, stream)
+                                        : launch_fast_variant3<EL, CT, false, false>(p, lds_bytes, stream);
 }
 
 hipError_t launch_sweep_fast(const SweepParams& p, size_t /*generic_lds_bytes*/, hipStream_t stream) {

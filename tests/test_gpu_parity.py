@@ -216,6 +216,50 @@ def test_two_steps_per_pass_equals_the_serial_chain(monkeypatch):
         assert_state_equal(g, o, 1)
 
 
+def test_four_steps_per_pass_equals_the_serial_chain(monkeypatch):
+    """Both block counts <= 16: the production kernel evaluates steps q .. q+3 in the four rows of the wave and commits them in
+    order as long as none of the earlier movers touched what the next one read.  Chains equal their
+    oracle runs sweep by sweep and equal the same kernel forced to two steps and to one step per pass -- on a graph with
+    m_r > 10^4 (closed-form log_q tiers), on the n_1000 data set (table tier), under a cooling schedule with the early
+    stop armed, and with chunks that end mid-pass."""
+    mh = B.MetropolisHasting()
+    n1000 = O.load_graph("n_1000")
+    big = _random_graph(8, 20_011, 17_003, 300_000, 12, 9)
+    for (rowptr, col, na, nb, ka, kb, eps), runs in (
+            ((big[0], big[1], 20_011, 17_003, 12, 9, 1.0), [("constant", [1.0], 2, BIG), ("constant", [0.6], 1, BIG)]),
+            ((n1000[0], n1000[1], 500, 500, 4, 6, 1.0), [("constant", [1.0], 20, BIG), ("exponential", [3.0, 0.9995], 10, 1500),
+                                                         ("abrupt_cool", [2600.0], 4, BIG), ("linear", [2.0, 1e-4], 6, BIG)])):
+        n = na + nb
+        lab = O.contiguous_labels(na, nb, ka, kb)
+        chains = 5
+        models = {}
+        for env in ("1", "2", None):  # one step per pass, two, four
+            if env is None:
+                monkeypatch.delenv("BISBM_SINGLE_STEPS", raising=False)
+            else:
+                monkeypatch.setenv("BISBM_SINGLE_STEPS", env)
+            m = gpu_model(rowptr, col, na, nb, ka, kb, eps, lab, n_chains=chains, rng="philox", seed=321)
+            m.shuffle_bisbm()
+            models[env] = (m, [np.atleast_1d(mh.anneal(m, s, kw, sweeps * n, aw)).copy() for s, kw, sweeps, aw in runs])
+        monkeypatch.delenv("BISBM_SINGLE_STEPS", raising=False)
+        g, rates = models[None]
+        for env in ("1", "2"):
+            h, rates_h = models[env]
+            for a, b in zip(rates, rates_h):
+                assert (a == b).all()
+            for c in range(chains):
+                assert (g.get_memberships(c) == h.get_memberships(c)).all()
+            assert (g.get_entropy() == h.get_entropy()).all()  # same sum, same order of additions
+        for c in (0, chains - 1):
+            o = O.OracleModel(rowptr, col, na, nb, ka, kb, eps, lab)
+            o.seed_philox(321, c)
+            o.shuffle_bisbm()
+            for (s, kw, sweeps, aw), r in zip(runs, rates):
+                assert o.anneal(s, kw, sweeps * n, aw) == r[c], (s, c)
+            assert_state_equal(g, o, c)
+            assert g.get_entropy()[c] == pytest.approx(o.get_entropy(), rel=1e-9)
+
+
 @pytest.mark.parametrize("roles", ["claims", "1", "2"])
 def test_either_wave_can_step(roles, monkeypatch):
     """The production kernel settles at start which of a workgroup's two waves steps (per-SIMD claims); whichever it is
