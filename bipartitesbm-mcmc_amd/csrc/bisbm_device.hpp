@@ -124,6 +124,28 @@ __device__ __forceinline__ double butterfly_rows16(double x) {
     return x;
 }
 
+// Eight 8-leaf butterflies at once, one per group of eight lanes: the first three levels of butterfly_sum (two quad permutes,
+// then lane i <-> 7 - i inside the group).  Every lane of a group ends up with its group's sum; same bits as the 64-leaf tree
+// whose leaves 8..63 are +0.0.
+__device__ __forceinline__ double butterfly_groups8(double x) {
+    x = x + dpp_f64<kDppXor1>(x);
+    x = x + dpp_f64<kDppXor2>(x);
+    x = x + dpp_f64<kDppHalfMirror>(x);
+    return x;
+}
+
+// inclusive prefix sum inside every group of eight lanes (lb = lane & 7): row_shr pulls across the middle of a 16-lane row, so
+// the lanes whose source lies in the neighbouring group add nothing
+__device__ __forceinline__ int group_inclusive_scan8(int x, uint32_t lb) {
+    const int s1 = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);  // row_shr:1
+    x += lb >= 1u ? s1 : 0;
+    const int s2 = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);  // row_shr:2
+    x += lb >= 2u ? s2 : 0;
+    const int s4 = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);  // row_shr:4
+    x += lb >= 4u ? s4 : 0;
+    return x;
+}
+
 // inclusive prefix sum inside every 16-lane row (row_shr never leaves its row)
 __device__ __forceinline__ int row_inclusive_scan16(int x) {
     x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);  // row_shr:1

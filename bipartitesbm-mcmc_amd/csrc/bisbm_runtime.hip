@@ -722,7 +722,7 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     p.fixed_stepping_wave = 0;
     {
         const char* single = getenv("BISBM_SINGLE_STEPS");  // =1: one step per pass in every variant (A/B checks, tests)
-        p.pair_steps = (single && single[0] == '1') ? 0u : (single && single[0] == '2') ? 1u : 2u;  // =2: two per pass at most
+        p.pair_steps = !single ? 3u : single[0] == '1' ? 0u : single[0] == '2' ? 1u : single[0] == '4' ? 2u : 3u;  // =2 / =4: at most two / four per pass
     }
     if (fast) {
         const char* fixed = getenv("BISBM_FIXED_ROLES");  // =1: wave 0 always steps, =2: wave 1 (A/B checks, tests)

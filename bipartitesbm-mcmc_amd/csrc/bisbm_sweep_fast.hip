@@ -112,8 +112,9 @@ constexpr uint32_t kRowCap = 255;     // longest row the feeder walks (a k_v cou
     __asm__ volatile("" : "+v"(name))
 
 // EL: eta in LDS.  CT: constant schedule.  K32: both block counts <= 32 (five-level scans and sums).  K16 (with K32): both
-// block counts <= 16: four steps per pass in the four 16-lane rows of the wave (step_quad).
-template <bool EL, bool CT, bool K32, bool K16>
+// block counts <= 16: four steps per pass in the four 16-lane rows of the wave (step_quad).  K8 (with K16): both <= 8: eight
+// steps per pass in groups of eight lanes (step_oct).
+template <bool EL, bool CT, bool K32, bool K16, bool K8>
 __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p) {
     extern __shared__ __align__(16) uint32_t lds32[];
     const uint32_t chain = blockIdx.x;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     if (is_main) __builtin_amdgcn_s_setprio(3);
     // lane <-> block: m_r / n_r of block i sit in lane i; the K <= 32 variants keep a second copy in lane 32 + i, so that
     // the upper half of the wave can run a step of its own (step_pair below); the K <= 16 variants keep four copies (step_quad)
-    const uint32_t lb = K16 ? (lane & 15u) : K32 ? (lane & 31u) : lane;
+    const uint32_t lb = K8 ? (lane & 7u) : K16 ? (lane & 15u) : K32 ? (lane & 31u) : lane;
     int mrA = lb < ka ? mr_g[lb] : 0, nrA = lb < ka ? nr_g[lb] : 0;
     int mrB = lb < kb ? mr_g[ka + lb] : 0, nrB = lb < kb ? nr_g[ka + lb] : 0;
     __syncthreads();
@@ -218,7 +219,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     // two steps per pass (step_pair): K <= 32 (a constant schedule at T = 0 takes the general step anyway);
     // p.pair_steps == 0 switches it off (A/B runs, tests); 2: four steps per pass where both block counts are <= 16
     const bool pair_mode = (uint32_t)__builtin_amdgcn_readfirstlane((K32 && (!CT || T_const > 0.) && p.pair_steps != 0) ? 1 : 0) != 0u;
-    const bool quad_mode = (uint32_t)__builtin_amdgcn_readfirstlane((K16 && (!CT || T_const > 0.) && p.pair_steps > 1u) ? 1 : 0) != 0u;
+    const bool quad_mode = (uint32_t)__builtin_amdgcn_readfirstlane((K16 && !K8 && (!CT || T_const > 0.) && p.pair_steps > 1u) ? 1 : 0) != 0u;
+    const bool oct_mode = (uint32_t)__builtin_amdgcn_readfirstlane((K8 && (!CT || T_const > 0.) && p.pair_steps > 2u) ? 1 : 0) != 0u;
     const uint32_t track_min =
         (uint32_t)__builtin_amdgcn_readfirstlane(((!CT || T_const < 1.) && p.steps_await <= p.duration) ? 1 : 0);
     // constants of the hot step (log_q closed form, accept filter)
@@ -271,8 +273,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
             // the one-step evaluations (step_general, step) sum lanes 0..31 or 0..63 as ONE step: only its first row carries
             // the scalar terms (with four copies per wave, K <= 16, lanes 16..23 would add them a second time)
             // (the other variants: the same registers as sign_tail / sign_q -- their one-step sums never reach a second copy)
-            const double sign_tail1 = K16 ? (lane < 16u ? sign_tail : 0.) : sign_tail;
-            const double sign_q1 = K16 ? (lane < 16u ? sign_q : 0.) : sign_q;
+            const double sign_tail1 = K16 ? (lane < 8u ? sign_tail : 0.) : sign_tail;
+            const double sign_q1 = K16 ? (lane < 8u ? sign_q : 0.) : sign_q;
             const int eoff_l = (lane & 7u) < 6 ? 1 : ((lane & 1u) ? 2 : 0);       // eta_r+1, eta_s+1, eta_r, eta_s+2
             const int dq_l = (lane & 2u) ? ((lane & 1u) ? 1 : -1) : 0;            // n_r - 1, n_s + 1 in lanes 2,3 (mod 4)
             const int dsgn_l = dq_l;                                              // -deg, +deg in the same lanes
@@ -1102,6 +1104,180 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     }
                     acc_l0 += (unsigned long long)acc_chunk;
                 };
+                // ---- eight steps per pass (both block counts <= 8) ----
+                // step_quad once more: group g of eight lanes evaluates step q + g.  The 28 pairwise tests fill the wave (lane
+                // 8 j + i: earlier step i, later step j), so byte j of their ballot is the set of earlier steps step j clashes
+                // with, and the commit chain tests one byte against the movers so far per step.
+                const uint32_t grp = lane >> 3;
+                auto step_oct = [&](auto tm, uint32_t q, uint32_t nst) -> uint32_t {  // nst: steps of this pass that exist (1..8)
+                    constexpr bool TM = decltype(tm)::value;
+                    const uint32_t qs = q + min(grp, nst - 1u);
+                    const int sel = (int)(qs << 2);
+                    const uint32_t prop = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)prop_l);
+                    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)v_l);
+                    const uint32_t pack = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)pack_l);
+                    const double u_acc = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(ud_acc)),
+                                                          __builtin_amdgcn_ds_bpermute(sel, __double2loint(ud_acc)));
+                    const uint32_t deg = pack & 255u, r_loc = (pack >> 8) & 63u, t_loc = pack >> 16;
+                    const int k = (int)hist8_cur[qs * kHistStride + lb];
+                    const uint32_t a_rt = mq_at(r_loc, lb);
+                    const int32_t m_rt_raw = mq[a_rt];
+                    const int w_piv = mq[mq_at(lb, t_loc)];
+                    const int nn_r = __builtin_amdgcn_ds_bpermute((int)(r_loc << 2), nr_own);
+                    const int32_t kmask = (0 - k) >> 31;
+                    const int32_t m_rt = m_rt_raw & kmask;
+                    const uint32_t kk = (uint32_t)k;
+                    const double L1 = tab_at(tab.lg, (uint32_t)(m_rt + 1));
+                    const double L3 = tab_at(tab.lg, (uint32_t)(m_rt + 1) - kk);
+                    __asm__ volatile("" ::: "memory");
+                    const int scan = group_inclusive_scan8(w_piv, lb);  // inverse CDF per group of eight (:627-628)
+                    const unsigned long long hit = __builtin_amdgcn_ballot_w64((uint32_t)scan > prop);
+                    const uint32_t field = (uint32_t)(hit >> (grp << 3)) & 0xffu;
+                    const uint32_t s_loc = min((uint32_t)__builtin_ctz(field | 0x100u), last_own);
+                    const bool valid = grp < nst;
+                    const bool self = s_loc == r_loc;
+                    const bool live = nn_r != 1;
+                    const bool warm = CT ? true : (((zeroT_mask >> qs) & 1ull) == 0ull);
+                    constexpr unsigned long long kGrpRep = 0x8080808080808080ull;  // one lane per group (its last)
+                    const unsigned long long b_can = __builtin_amdgcn_ballot_w64(valid && live && !self) & kGrpRep;
+                    const unsigned long long b_selfok = __builtin_amdgcn_ballot_w64(valid && live && self && warm) & kGrpRep;
+                    if (b_can == 0ull) {
+                        acc_chunk += (uint32_t)__builtin_popcountll(b_selfok);
+                        return nst;
+                    }
+                    unsigned long long clash_bits;  // byte j, bit i: step i (earlier), if it moves, touches what step j read
+                    {
+                        const int li = (int)((lane & 7u) << 5), lj = (int)((lane >> 3) << 5);  // lane 8 i, lane 8 j
+                        const uint32_t r_i = (uint32_t)__builtin_amdgcn_ds_bpermute(li, (int)r_loc);
+                        const uint32_t s_i = (uint32_t)__builtin_amdgcn_ds_bpermute(li, (int)s_loc);
+                        const uint32_t r_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)r_loc);
+                        const uint32_t s_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)s_loc);
+                        const uint32_t t_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)t_loc);
+                        const uint32_t k_i_tj = (uint32_t)__builtin_amdgcn_ds_bpermute(li + (int)(t_j << 2), (int)kk);
+                        const uint32_t set_i = (1u << r_i) | (1u << s_i), set_j = (1u << r_j) | (1u << s_j);
+                        const uint32_t lo = min(r_i, s_i), hi = max(r_i, s_i);
+                        const uint32_t between = ((1u << hi) - 1u) & ~((2u << lo) - 1u);
+                        const bool clash = (set_i & set_j) != 0u || (((between >> s_j) & 1u) != 0u && k_i_tj != 0u);
+                        clash_bits = __builtin_amdgcn_ballot_w64(clash);
+                    }
+                    const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);
+                    const uint32_t a_st = mq_at(s_loc, lb);
+                    const int32_t m_st_raw = mq[a_st];
+                    const uint32_t e_idx = (own_base + idx_l) * D + deg;
+                    const int ee = (int)eta_rd(e_idx);
+                    const int mm = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), mr_own);
+                    const int nn = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), nr_own);
+                    const int32_t m_st = m_st_raw & kmask;
+                    const int ideg = (int)deg;
+                    const int qn = mm + __mul24(ideg, dsgn_l);
+                    const uint32_t tail_idx = (uint32_t)((qn ^ ((qn ^ ee) & eta_mask_l)) + toff_l);
+                    const int qk = nn + dq_l;
+                    const double tail_lg = tab_at(tab.lg, tail_idx);
+                    const double logn = tab_at(tab.logtab, (uint32_t)qn);
+                    const double L2 = tab_at(tab.lg, (uint32_t)(m_st + 1));
+                    const double L4 = tab_at(tab.lg, (uint32_t)(m_st + 1) + kk);
+                    const double a0 = k * (m_st + eps) * inv_oth;
+                    const double a1 = k * (m_rt - k + eps) * inv_oth;
+                    const double accu0 = butterfly_groups8(a0);
+                    const double accu1 = butterfly_groups8(a1);
+                    double lq;
+                    {
+                        const int qk2 = qk < qn ? qk : qn;
+                        const double nd = (double)qn, kd = (double)qk2;
+                        const double k2 = kd * kd;
+                        const bool direct = qn > kQNmax && k2 > c_576 * nd;
+                        if (__builtin_amdgcn_ballot_w64(qn > kQNmax) == 0) {
+                            lq = log_q_table(tab, qn, qk2);
+                        } else if (__builtin_amdgcn_ballot_w64(!direct) == 0) {
+                            double sq, rr;
+                            sqrt_rsqrt(nd, sq, rr);
+                            lq = log_q_closed(kd, sq, rr, logn, lqc);
+                        } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= c_169 * nd)) == 0) {
+                            double sq, rr;
+                            sqrt_rsqrt(nd, sq, rr);
+                            lq = log_q_closed2(kd, sq, rr, logn, lqc);
+                        } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= ldexp(nd, 6))) == 0) {
+                            double sq, rr;
+                            sqrt_rsqrt(nd, sq, rr);
+                            const double lq_mid = log_q_mid(kd, sq, rr, logn, lqc);
+                            const double lq_far = log_q_closed(kd, sq, rr, logn, lqc);
+                            lq = direct ? lq_far : lq_mid;
+                        } else {
+                            lq = log_q<true>(tab, qn, qk, logn);
+                        }
+                    }
+                    double d = (L1 + L2) - (L3 + L4);
+                    d = d + tail_lg * sign_tail;
+                    d = d + lq * sign_q;
+                    const double dS = butterfly_groups8(d);
+                    double invT = invT_const;
+                    if (!CT) invT = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(invT_l)),
+                                                     __builtin_amdgcn_ds_bpermute(sel, __double2loint(invT_l)));
+                    const double z = -dS * invT;
+                    const double est = accu1 * exp2_filter(z * c_l2e);
+                    const double lhs = u_acc * accu0;
+                    unsigned long long b_acc = __builtin_amdgcn_ballot_w64(warm ? lhs < est : dS < 0.);
+                    const unsigned long long b_far = __builtin_amdgcn_ballot_w64(!warm || fabs(lhs - est) > c_tol * est);
+                    if (__builtin_expect((~b_far & b_can) != 0ull, 0)) {
+                        const unsigned long long exact = __builtin_amdgcn_ballot_w64(lhs < accu1 * exp(z));
+                        b_acc = (b_acc & b_far) | (exact & ~b_far);
+                    }
+                    // bits 7 / 15 / ... / 63 -> bits 0..7
+                    auto groups8 = [](unsigned long long b) -> uint32_t { return (uint32_t)(((b >> 7) * 0x0102040810204081ull) >> 56) & 0xffu; };
+                    const uint32_t can8 = groups8(b_can), mv8 = can8 & groups8(b_acc & kGrpRep), selfok8 = groups8(b_selfok);
+                    uint32_t moved = mv8 & 1u, commit = 1u, stands = 1u;
+#pragma unroll
+                    for (uint32_t j = 1; j < 8u; ++j) {  // step j stands: it exists, every earlier one stood, no earlier mover clashes
+                        const uint32_t clash_j = (uint32_t)(clash_bits >> (8u * j)) & moved;
+                        stands &= (nst > j ? 1u : 0u) & (clash_j == 0u ? 1u : 0u);
+                        commit |= stands << j;
+                        moved |= (stands & (mv8 >> j) & 1u) << j;
+                    }
+                    acc_chunk += (uint32_t)__builtin_popcount(moved | (commit & selfok8));
+                    if (moved != 0u) {
+                        unsigned long long movers = 0ull;  // all eight lanes of every mover's group
+#pragma unroll
+                        for (uint32_t g = 0; g < 8u; ++g)
+                            if ((moved >> g) & 1u) movers |= 0xffull << (8u * g);
+                        wfence();
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & lanes_koth)) {
+                            mq[a_rt] = m_rt_raw - k;
+                            mq[a_st] = m_st_raw + k;
+                        }
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x3030303030303030ull))  // lanes 4, 5 of a group: eta_r - 1, eta_s + 1
+                            eta_wr(e_idx, (uint32_t)(ee + ((int)(lb & 1u) * 2 - 1)));
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0101010101010101ull)) labels[v] = (uint8_t)(own_base + s_loc);
+#pragma unroll
+                        for (uint32_t g = 0; g < 8u; ++g) {
+                            if ((moved >> g) & 1u) {
+                                const uint32_t rg = readlane(r_loc, 8u * g), sg = readlane(s_loc, 8u * g), dg = readlane(deg, 8u * g);
+                                const int dl = (int)min(lb ^ rg, 1u) - (int)min(lb ^ sg, 1u);
+                                mr_own += __mul24((int)dg, dl);
+                                nr_own += dl;
+                                cum_l0 += readlane(dS, 8u * g + 7u);
+                                if constexpr (TM) new_minimum(q + g);
+                            }
+                        }
+                        wfence();
+                    }
+                    return (uint32_t)__builtin_popcount(commit);
+                };
+                auto oct_loop = [&](auto tm) {
+                    const unsigned long long gen_mask = __builtin_amdgcn_ballot_w64((int32_t)prop_l < 0);
+                    uint32_t q = 0;
+                    acc_chunk = 0;
+                    while (q < cnt) {
+                        const uint32_t eight = (uint32_t)(gen_mask >> q) & 0xffu;
+                        if (__builtin_expect((eight & 1u) != 0u, 0)) {
+                            step_general(q, CT ? T_const : readlane(T_l, q));
+                            q += 1u;
+                        } else {
+                            const uint32_t nst = min(min((uint32_t)__builtin_ctz(eight | 0x100u), 8u), cnt - q);
+                            q += step_oct(tm, q, nst);
+                        }
+                    }
+                    acc_l0 += (unsigned long long)acc_chunk;
+                };
                 // steps that need the general path (bit 31 of prop_l) go one at a time
                 auto pair_loop = [&](auto tm) {
                     const unsigned long long gen_mask = __builtin_amdgcn_ballot_w64((int32_t)prop_l < 0);
@@ -1118,7 +1294,12 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     }
                     acc_l0 += (unsigned long long)acc_chunk;
                 };
-                if (K16 && quad_mode) {
+                if (K8 && oct_mode) {
+                    if (track_min != 0u)
+                        oct_loop(std::true_type{});
+                    else
+                        oct_loop(std::false_type{});
+                } else if (K16 && quad_mode) {
                     if (track_min != 0u)
                         quad_loop(std::true_type{});
                     else
@@ -1212,20 +1393,21 @@ size_t sweep_fast_lds_bytes(uint32_t ka, uint32_t kb, uint32_t maxdeg, bool eta_
     return ((dwords > reach ? dwords : reach) * 4 + 15) & ~(size_t)15;
 }
 
-template <bool EL, bool CT, bool K32, bool K16>
+template <bool EL, bool CT, bool K32, bool K16, bool K8>
 static hipError_t launch_fast_variant3(const SweepParams& p, size_t lds_bytes, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)sweep_fast_kernel<EL, CT, K32, K16>,
+    hipError_t e = hipFuncSetAttribute((const void*)sweep_fast_kernel<EL, CT, K32, K16, K8>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((sweep_fast_kernel<EL, CT, K32, K16>), dim3(p.n_chains), dim3(2 * kWave), lds_bytes, stream, p);
+    hipLaunchKernelGGL((sweep_fast_kernel<EL, CT, K32, K16, K8>), dim3(p.n_chains), dim3(2 * kWave), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
 template <bool EL, bool CT>
 static hipError_t launch_fast_variant(const SweepParams& p, size_t lds_bytes, hipStream_t stream) {
-    if (p.ka <= 16u && p.kb <= 16u && p.pair_steps > 1u) return launch_fast_variant3<EL, CT, true, true>(p, lds_bytes, stream);
-    return (p.ka <= 32u && p.kb <= 32u) ? launch_fast_variant3<EL, CT, true, false>(p, lds_bytes, stream)
-                                        : launch_fast_variant3<EL, CT, false, false>(p, lds_bytes, stream);
+    if (p.ka <= 8u && p.kb <= 8u && p.pair_steps > 2u) return launch_fast_variant3<EL, CT, true, true, true>(p, lds_bytes, stream);
+    if (p.ka <= 16u && p.kb <= 16u && p.pair_steps > 1u) return launch_fast_variant3<EL, CT, true, true, false>(p, lds_bytes, stream);
+    return (p.ka <= 32u && p.kb <= 32u) ? launch_fast_variant3<EL, CT, true, false, false>(p, lds_bytes, stream)
+                                        : launch_fast_variant3<EL, CT, false, false, false>(p, lds_bytes, stream);
 }
 
 hipError_t launch_sweep_fast(const SweepParams& p, size_t /*generic_lds_bytes*/, hipStream_t stream) {
