@@ -1223,7 +1223,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         b_acc = (b_acc & b_far) | (exact & ~b_far);
                     }
                     // bits 7 / 15 / ... / 63 -> bits 0..7
-                    auto groups8 = [](unsigned long long b) -> uint32_t { return (uint32_t)(((b >> 7) * 0x0102040810204081ull) >> 56) & 0xffu; };
+                    auto groups8 = [](unsigned long long b) -> uint32_t { return (uint32_t)(((b >> 7) * 0x0102040810204080ull) >> 56) & 0xffu; };
                     const uint32_t can8 = groups8(b_can), mv8 = can8 & groups8(b_acc & kGrpRep), selfok8 = groups8(b_selfok);
                     uint32_t moved = mv8 & 1u, commit = 1u, stands = 1u;
 #pragma unroll
