@@ -216,24 +216,27 @@ def test_two_steps_per_pass_equals_the_serial_chain(monkeypatch):
         assert_state_equal(g, o, 1)
 
 
-def test_four_steps_per_pass_equals_the_serial_chain(monkeypatch):
-    """Both block counts <= 16: the production kernel evaluates steps q .. q+3 in the four rows of the wave and commits them in
-    order as long as none of the earlier movers touched what the next one read.  Chains equal their
-    oracle runs sweep by sweep and equal the same kernel forced to two steps and to one step per pass -- on a graph with
-    m_r > 10^4 (closed-form log_q tiers), on the n_1000 data set (table tier), under a cooling schedule with the early
-    stop armed, and with chunks that end mid-pass."""
+def test_four_and_eight_steps_per_pass_equal_the_serial_chain(monkeypatch):
+    """Both block counts <= 16 (<= 8): the production kernel evaluates steps q .. q+3 (q+7) in the four rows (eight groups of
+    eight lanes) of the wave and commits them in order as long as none of the earlier movers touched what the next one read
+    (DESIGN.md section 6).  Chains equal their oracle runs sweep by sweep and equal the same kernel held to four, two and
+    one step per pass -- on graphs with m_r > 10^4 (closed-form log_q tiers; 12 + 9 blocks: four per pass, 5 + 7: eight), on
+    the n_1000 data set (4 + 6 blocks, table tier: eight per pass), under cooling schedules with the early stop armed, and
+    with chunks that end mid-pass."""
     mh = B.MetropolisHasting()
     n1000 = O.load_graph("n_1000")
     big = _random_graph(8, 20_011, 17_003, 300_000, 12, 9)
+    big8 = _random_graph(9, 20_011, 17_003, 300_000, 5, 7)
     for (rowptr, col, na, nb, ka, kb, eps), runs in (
             ((big[0], big[1], 20_011, 17_003, 12, 9, 1.0), [("constant", [1.0], 2, BIG), ("constant", [0.6], 1, BIG)]),
+            ((big8[0], big8[1], 20_011, 17_003, 5, 7, 0.5), [("constant", [1.0], 2, BIG), ("abrupt_cool", [50_000.0], 2, BIG)]),
             ((n1000[0], n1000[1], 500, 500, 4, 6, 1.0), [("constant", [1.0], 20, BIG), ("exponential", [3.0, 0.9995], 10, 1500),
                                                          ("abrupt_cool", [2600.0], 4, BIG), ("linear", [2.0, 1e-4], 6, BIG)])):
         n = na + nb
         lab = O.contiguous_labels(na, nb, ka, kb)
         chains = 5
         models = {}
-        for env in ("1", "2", None):  # one step per pass, two, four
+        for env in ("1", "2", "4", None):  # one step per pass, two, at most four, all the variant allows
             if env is None:
                 monkeypatch.delenv("BISBM_SINGLE_STEPS", raising=False)
             else:
@@ -243,7 +246,7 @@ def test_four_steps_per_pass_equals_the_serial_chain(monkeypatch):
             models[env] = (m, [np.atleast_1d(mh.anneal(m, s, kw, sweeps * n, aw)).copy() for s, kw, sweeps, aw in runs])
         monkeypatch.delenv("BISBM_SINGLE_STEPS", raising=False)
         g, rates = models[None]
-        for env in ("1", "2"):
+        for env in ("1", "2", "4"):
             h, rates_h = models[env]
             for a, b in zip(rates, rates_h):
                 assert (a == b).all()
