@@ -70,7 +70,6 @@ struct SweepParams {
     // production kernel: 0 = one step per pass; 1 = two consecutive steps per pass where both block counts are <= 32;
     // 2 = also four per pass where both are <= 16; 3 = also eight per pass where both are <= 8
     uint32_t pair_steps;
-    uint32_t pair_vector;  // trial: the two-steps pass in the vector formulation of step_quad (BISBM_PAIR_VECTOR=1)
     // wide mode (KA + KB > 256; generic kernel only): `labels` holds two-byte labels (label_stride counts labels, not
     // bytes), and the a x b quadrant of m is read and updated in HBM
     uint32_t wide;

@@ -722,10 +722,6 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     p.fixed_stepping_wave = 0;
     {
         const char* single = getenv("BISBM_SINGLE_STEPS");  // =1: one step per pass in every variant (A/B checks, tests)
-        {
-            const char* pv = getenv("BISBM_PAIR_VECTOR");
-            p.pair_vector = (pv && pv[0] == '1') ? 1u : 0u;
-        }
         p.pair_steps = !single ? 3u : single[0] == '1' ? 0u : single[0] == '2' ? 1u : single[0] == '4' ? 2u : 3u;  // =2 / =4: at most two / four per pass
     }
     if (fast) {

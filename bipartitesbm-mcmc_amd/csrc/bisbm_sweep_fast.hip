@@ -911,184 +911,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     return 1u + stands;
                 };
 
-                // ---- two steps per pass, the vector formulation of step_quad for two halves of 32 lanes (trial: BISBM_PAIR_VECTOR=1) ----
-                // The same idea one level further: row g of the wave (lanes 16 g .. 16 g + 15, one lane per block) evaluates
-                // step q + g against the state before step q.  Steps are committed in order as long as each one's
-                // evaluation stands, i.e. no step committed before it in this pass moved its node AND touched what it
-                // read (the rule of step_pair, applied to every earlier mover: their writes touch disjoint rows, so the
-                // conditions compose); the first step that does not stand opens the next pass.  The six pairwise tests
-                // are evaluated lane-parallel (lane 4 i + j: steps i and j) and arrive as one 16-bit word.
-                const uint32_t half2 = lane >> 5;
-                auto step_duo = [&](auto tm, uint32_t q, uint32_t nst) -> uint32_t {  // nst: steps of this pass that exist (1..2)
-                    constexpr bool TM = decltype(tm)::value;
-                    const uint32_t qs = q + min(half2, nst - 1u);  // (rows past nst repeat the last step; their results are ignored)
-                    const int sel = (int)(qs << 2);
-                    const uint32_t prop = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)prop_l);
-                    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)v_l);
-                    const uint32_t pack = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)pack_l);
-                    const double u_acc = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(ud_acc)),
-                                                          __builtin_amdgcn_ds_bpermute(sel, __double2loint(ud_acc)));
-                    const uint32_t deg = pack & 255u, r_loc = (pack >> 8) & 63u, t_loc = pack >> 16;
-                    const int k = (int)hist8_cur[qs * kHistStride + lb];
-                    const uint32_t a_rt = mq_at(r_loc, lb);
-                    const int32_t m_rt_raw = mq[a_rt];
-                    const int w_piv = mq[mq_at(lb, t_loc)];
-                    const int nn_r = __builtin_amdgcn_ds_bpermute((int)(r_loc << 2), nr_own);
-                    const int32_t kmask = (0 - k) >> 31;
-                    const int32_t m_rt = m_rt_raw & kmask;
-                    const uint32_t kk = (uint32_t)k;
-                    const double L1 = tab_at(tab.lg, (uint32_t)(m_rt + 1));
-                    const double L3 = tab_at(tab.lg, (uint32_t)(m_rt + 1) - kk);
-                    __asm__ volatile("" ::: "memory");
-                    // inverse CDF per row (:627-628): the row_shr scan does not leave its 16 lanes
-                    const int scan = wave_inclusive_scan32(w_piv);
-                    const unsigned long long hit = __builtin_amdgcn_ballot_w64((uint32_t)scan > prop);
-                    const uint32_t field = (uint32_t)(hit >> (half2 << 5));
-                    const uint32_t s_loc = min((uint32_t)__builtin_ctzll((unsigned long long)field | (1ull << 32)), last_own);
-                    const bool valid = half2 < nst;
-                    const bool self = s_loc == r_loc;
-                    const bool live = nn_r != 1;  // (:467-471: a block is never emptied)
-                    const bool warm = CT ? true : (((zeroT_mask >> qs) & 1ull) == 0ull);  // T = 0: r == s is not accepted (:49-50)
-                    constexpr unsigned long long kRowRep = 0x8000000080000000ull;  // one lane per half (its last)
-                    const unsigned long long b_can = __builtin_amdgcn_ballot_w64(valid && live && !self) & kRowRep;
-                    const unsigned long long b_selfok = __builtin_amdgcn_ballot_w64(valid && live && self && warm) & kRowRep;
-                    if (b_can == 0ull) {  // every step of the pass is an r == s (or a vetoed one): nothing changes (:109-112)
-                        acc_chunk += (uint32_t)__builtin_popcountll(b_selfok);
-                        return nst;
-                    }
-                    // would step q, if it moves its node, touch what step q + 1 read?  (every lane computes the same answer)
-                    uint32_t clash_bits;
-                    {
-                        const uint32_t r_i = (uint32_t)__builtin_amdgcn_ds_bpermute(0, (int)r_loc);
-                        const uint32_t s_i = (uint32_t)__builtin_amdgcn_ds_bpermute(0, (int)s_loc);
-                        const uint32_t r_j = (uint32_t)__builtin_amdgcn_ds_bpermute(128, (int)r_loc);
-                        const uint32_t s_j = (uint32_t)__builtin_amdgcn_ds_bpermute(128, (int)s_loc);
-                        const uint32_t t_j = (uint32_t)__builtin_amdgcn_ds_bpermute(128, (int)t_loc);
-                        const uint32_t k_i_tj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(t_j << 2), (int)kk);  // k of step q at block t'
-                        const uint32_t set_i = (1u << r_i) | (1u << s_i), set_j = (1u << r_j) | (1u << s_j);
-                        const uint32_t lo = min(r_i, s_i), hi = max(r_i, s_i);
-                        const uint32_t between = ((1u << hi) - 1u) & ~((2u << lo) - 1u);
-                        const bool clash = (set_i & set_j) != 0u || (((between >> s_j) & 1u) != 0u && k_i_tj != 0u);
-                        clash_bits = (uint32_t)__builtin_amdgcn_ballot_w64(clash) & 1u;
-                    }
-                    const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
-                    const uint32_t a_st = mq_at(s_loc, lb);
-                    const int32_t m_st_raw = mq[a_st];
-                    const uint32_t e_idx = (own_base + idx_l) * D + deg;
-                    const int ee = (int)eta_rd(e_idx);
-                    const int mm = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), mr_own);
-                    const int nn = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), nr_own);
-                    const int32_t m_st = m_st_raw & kmask;
-                    const int ideg = (int)deg;
-                    const int qn = mm + __mul24(ideg, dsgn_l);        // m0r, m0s, m0r - deg, m0s + deg
-                    const uint32_t tail_idx = (uint32_t)((qn ^ ((qn ^ ee) & eta_mask_l)) + toff_l);
-                    const int qk = nn + dq_l;
-                    const double tail_lg = tab_at(tab.lg, tail_idx);
-                    const double logn = tab_at(tab.logtab, (uint32_t)qn);
-                    const double L2 = tab_at(tab.lg, (uint32_t)(m_st + 1));
-                    const double L4 = tab_at(tab.lg, (uint32_t)(m_st + 1) + kk);
-                    const double a0 = k * (m_st + eps) * inv_oth;
-                    const double a1 = k * (m_rt - k + eps) * inv_oth;
-                    const double accu0 = butterfly_rows32(a0);  // every lane of a row: the row's sum
-                    const double accu1 = butterfly_rows32(a1);
-                    double lq;
-                    {
-                        const int qk2 = qk < qn ? qk : qn;
-                        const double nd = (double)qn, kd = (double)qk2;
-                        const double k2 = kd * kd;
-                        const bool direct = qn > kQNmax && k2 > c_576 * nd;
-                        if (__builtin_amdgcn_ballot_w64(qn > kQNmax) == 0) {
-                            lq = log_q_table(tab, qn, qk2);  // small graphs: every argument inside the table (int_part.hh:27-37)
-                        } else if (__builtin_amdgcn_ballot_w64(!direct) == 0) {
-                            double sq, rr;
-                            sqrt_rsqrt(nd, sq, rr);
-                            lq = log_q_closed(kd, sq, rr, logn, lqc);
-                        } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= c_169 * nd)) == 0) {
-                            double sq, rr;
-                            sqrt_rsqrt(nd, sq, rr);
-                            lq = log_q_closed2(kd, sq, rr, logn, lqc);
-                        } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= ldexp(nd, 6))) == 0) {
-                            double sq, rr;
-                            sqrt_rsqrt(nd, sq, rr);
-                            const double lq_mid = log_q_mid(kd, sq, rr, logn, lqc);
-                            const double lq_far = log_q_closed(kd, sq, rr, logn, lqc);
-                            lq = direct ? lq_far : lq_mid;
-                        } else {
-                            lq = log_q<true>(tab, qn, qk, logn);
-                        }
-                    }
-                    double d = (L1 + L2) - (L3 + L4);
-                    d = d + tail_lg * sign_tail;
-                    d = d + lq * sign_q;
-                    const double dS = butterfly_rows32(d);
-                    // accept (:47-61), per row
-                    double invT = invT_const;
-                    if (!CT) invT = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(invT_l)),
-                                                     __builtin_amdgcn_ds_bpermute(sel, __double2loint(invT_l)));
-                    const double z = -dS * invT;
-                    const double est = accu1 * exp2_filter(z * c_l2e);
-                    const double lhs = u_acc * accu0;
-                    unsigned long long b_acc = __builtin_amdgcn_ballot_w64(warm ? lhs < est : dS < 0.);  // T = 0: dS < 0 decides (:49-50)
-                    const unsigned long long b_far = __builtin_amdgcn_ballot_w64(!warm || fabs(lhs - est) > c_tol * est);
-                    if (__builtin_expect((~b_far & b_can) != 0ull, 0)) {  // a verdict too close to call
-                        const unsigned long long exact = __builtin_amdgcn_ballot_w64(lhs < accu1 * exp(z));
-                        b_acc = (b_acc & b_far) | (exact & ~b_far);
-                    }
-                    // verdicts, in step order: bits 15 / 31 / 47 / 63 -> bits 0..3
-                    auto rows2 = [](unsigned long long b) -> uint32_t { return ((uint32_t)(b >> 31) & 1u) | ((uint32_t)(b >> 62) & 2u); };
-                    const uint32_t can4 = rows2(b_can), mv4 = can4 & rows2(b_acc & kRowRep), selfok4 = rows2(b_selfok);
-                    uint32_t moved = mv4 & 1u, commit = 1u;
-                    {
-                        const uint32_t k1 = sflag(nst - 1u) & ((moved & clash_bits) ^ 1u);
-                        commit |= k1 << 1;
-                        moved |= (k1 & (mv4 >> 1) & 1u) << 1;
-                    }
-                    acc_chunk += (uint32_t)__builtin_popcount(moved | (commit & selfok4));
-                    if (moved != 0u) {
-                        // ---- apply_mcmc_moves, blockmodel.cc:461-503, for the steps that move: their rows of m differ ----
-                        unsigned long long movers = 0ull;
-                        if (moved & 1u) movers |= 0x00000000ffffffffull;
-                        if (moved & 2u) movers |= 0xffffffff00000000ull;
-                        wfence();
-                        if (__builtin_amdgcn_inverse_ballot_w64(movers & lanes_koth)) {  // k == 0: rewrites the same values
-                            mq[a_rt] = m_rt_raw - k;
-                            mq[a_st] = m_st_raw + k;
-                        }
-                        if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000003000000030ull))  // lanes 4, 5 of a half: eta_r - 1, eta_s + 1
-                            eta_wr(e_idx, (uint32_t)(ee + ((int)(lb & 1u) * 2 - 1)));
-                        if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000000100000001ull)) labels[v] = (uint8_t)(own_base + s_loc);
-                        // the register copies of m_r / n_r, sum dS (:500) and the early-stop bookkeeping, in step order
-#pragma unroll
-                        for (uint32_t g = 0; g < 2u; ++g) {
-                            if ((moved >> g) & 1u) {
-                                const uint32_t rg = readlane(r_loc, 32u * g), sg = readlane(s_loc, 32u * g), dg = readlane(deg, 32u * g);
-                                const int dl = (int)min(lb ^ rg, 1u) - (int)min(lb ^ sg, 1u);  // +1 on lane s, -1 on lane r
-                                mr_own += __mul24((int)dg, dl);
-                                nr_own += dl;
-                                cum_l0 += readlane(dS, 32u * g + 31u);
-                                if constexpr (TM) new_minimum(q + g);
-                            }
-                        }
-                        wfence();
-                    }
-                    return (uint32_t)__builtin_popcount(commit);
-                };
-                auto duo_loop = [&](auto tm) {
-                    const unsigned long long gen_mask = __builtin_amdgcn_ballot_w64((int32_t)prop_l < 0);
-                    uint32_t q = 0;
-                    acc_chunk = 0;
-                    while (q < cnt) {
-                        const uint32_t two = (uint32_t)(gen_mask >> q) & 3u;
-                        if (__builtin_expect((two & 1u) != 0u, 0)) {
-                            step_general(q, CT ? T_const : readlane(T_l, q));
-                            q += 1u;
-                        } else {
-                            const uint32_t nst = min(2u - (two >> 1), cnt - q);
-                            q += step_duo(tm, q, nst);
-                        }
-                    }
-                    acc_l0 += (unsigned long long)acc_chunk;
-                };
                 // ---- four steps per pass (both block counts <= 16) ----
                 // The same idea one level further: row g of the wave (lanes 16 g .. 16 g + 15, one lane per block) evaluates
                 // step q + g against the state before step q.  Steps are committed in order as long as each one's
@@ -1482,11 +1304,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         quad_loop(std::true_type{});
                     else
                         quad_loop(std::false_type{});
-                } else if (K32 && !K16 && pair_mode && p.pair_vector != 0u) {
-                    if (track_min != 0u)
-                        duo_loop(std::true_type{});
-                    else
-                        duo_loop(std::false_type{});
                 } else if (K32 && pair_mode) {
                     if (track_min != 0u)
                         pair_loop(std::true_type{});
