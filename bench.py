@@ -57,6 +57,11 @@ def parse_args(argv=None):
     ap.add_argument("--edges", type=int, default=10_000_000)
     ap.add_argument("--ka", type=int, default=32)
     ap.add_argument("--kb", type=int, default=32)
+    ap.add_argument("--edgelist", default=None,
+                    help="run on this edge-list file instead of the synthetic graph (--na / --nb give the type sizes, --ka / --kb the "
+                         "blocks of the contiguous initial partition); --edgelist n_1000 = the reference's shipped 1000-node data "
+                         "set as BASELINE configs[1] runs it (Ka = 4, Kb = 6, 256 chains, 2000 sweeps per step)")
+    ap.add_argument("--sweeps-per-step", type=int, default=1, help="sweeps of every chain per timed step (small graphs: one launch should last milliseconds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra legs after the timed region (equilibrated-start figure, pooling timings)")
@@ -108,9 +113,28 @@ def self_launch(args):
 
 
 # ----------------------------------------------------------------------------------------------- workload
+def apply_presets(args):
+    """--edgelist n_1000: BASELINE configs[1] (the shipped data set, copied as a fixture under tests/golden/)."""
+    if args.edgelist == "n_1000":
+        args.edgelist = os.path.join(ROOT, "tests", "golden", "bisbm-n_1000-ka_4-kb_6.edgelist")
+        args.preset = "BASELINE configs[1]"
+        args.na, args.nb, args.ka, args.kb = 500, 500, 4, 6
+        if args.chains == 1024:
+            args.chains = 256
+        if args.sweeps_per_step == 1:
+            args.sweeps_per_step = 2000
+    else:
+        args.preset = None
+    return args
+
+
 def make_graph(args, pkg, syn):
     na, nb, ka, kb, E = args.na, args.nb, args.ka, args.kb, args.edges
     n = na + nb
+    if args.edgelist:
+        rowptr, col = pkg.load_graph(args.edgelist, n)
+        args.edges = int(rowptr[-1]) // 2
+        return rowptr, col, syn.contiguous_labels(na, nb, ka, kb)
     a, b = syn.planted_edges(na, nb, E, ka, kb, seed=1)
     planted = syn.contiguous_labels(na, nb, ka, kb)  # the generator's own partition
     if args.shuffle_ids:
@@ -131,6 +155,10 @@ def make_graph(args, pkg, syn):
 REF_PROBE = {"reference_updates_per_s": 2.27e5, "port_updates_per_s_same_cpu": 9.9e5,
              "cpu": "Intel Xeon Processor @ 2.10GHz (build container, 1 core)",
              "source": "SURVEY.md section 6 [probe] (reference TUs -O3, anneal() only, 5 sweeps) and DESIGN.md section 7"}
+# ... and on the shipped n_1000 data set (Ka = 4, Kb = 6, T = 1): 3.4e6 updates/s; the port on the same CPU: 5.0e6
+REF_PROBE_N1000 = {"reference_updates_per_s": 3.4e6, "port_updates_per_s_same_cpu": 5.0e6,
+                   "cpu": "Intel Xeon Processor @ 2.10GHz (build container, 1 core)",
+                   "source": "SURVEY.md section 6 [probe] (n_1000, 2e6 steps) and the port timed in the same container"}
 
 
 def _cpu_model():
@@ -150,9 +178,13 @@ def cpu_worker(args):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     syn = importlib.import_module("bipartitesbm-mcmc_amd.synthetic")
+    args = apply_presets(args)
     na, nb, ka, kb = args.na, args.nb, args.ka, args.kb
     n = na + nb
-    a, b = syn.planted_edges(na, nb, args.edges, ka, kb, seed=1)
+    if args.edgelist:
+        a, b = O.load_edge_list(args.edgelist)
+    else:
+        a, b = syn.planted_edges(na, nb, args.edges, ka, kb, seed=1)
     rowptr, col = O.edge_to_csr(a, b, n)
     del a, b
     m = O.OracleModel(rowptr, col, na, nb, ka, kb, 1.0, syn.contiguous_labels(na, nb, ka, kb))
@@ -165,7 +197,7 @@ def cpu_worker(args):
     m.anneal("constant", [1.0], n, 1 << 60)  # one sweep to size the sample
     dt = time.perf_counter() - t0
     steps = n
-    extra = int(max(0, min(50, (budget - dt) // max(dt, 1e-9))))
+    extra = int(max(0, min(max(50, 20_000_000 // n), (budget - dt) // max(dt, 1e-9))))
     if extra > 0:
         t0 = time.perf_counter()
         m.anneal("constant", [1.0], extra * n, 1 << 60)
@@ -174,7 +206,7 @@ def cpu_worker(args):
     print(json.dumps({"steps": steps, "seconds": dt}), flush=True)
 
 
-def cpu_baseline(n, seconds_budget=18.0):
+def cpu_baseline(n, seconds_budget=18.0, probe=None):
     """`cores` independent single-chain processes of the oracle, one per host core, timed together (the reference is
     single-threaded: its multi-core figure is one process per core).  value = their summed rate."""
     cores = max(1, min(os.cpu_count() or 1, 16))
@@ -205,9 +237,9 @@ def cpu_baseline(n, seconds_budget=18.0):
                       "sweeps each of the same graph, anneal() wall time only, %.1f s" % (
                           cores, min(r["steps"] for r in res) // n, max(r["steps"] for r in res) // n,
                           max(r["seconds"] for r in res)),
-            "ratio_to_reference": REF_PROBE["port_updates_per_s_same_cpu"] / REF_PROBE["reference_updates_per_s"],
-            "reference_estimate_updates_per_s": total * REF_PROBE["reference_updates_per_s"] / REF_PROBE["port_updates_per_s_same_cpu"],
-            "reference_probe": REF_PROBE}
+            "ratio_to_reference": (probe or REF_PROBE)["port_updates_per_s_same_cpu"] / (probe or REF_PROBE)["reference_updates_per_s"],
+            "reference_estimate_updates_per_s": total * (probe or REF_PROBE)["reference_updates_per_s"] / (probe or REF_PROBE)["port_updates_per_s_same_cpu"],
+            "reference_probe": probe or REF_PROBE}
 
 
 # ----------------------------------------------------------------------------------------------- main
@@ -223,6 +255,7 @@ def main():
     args = parse_args()
     if args.cpu_worker > 0:
         return cpu_worker(args)
+    args = apply_presets(args)
     in_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not in_launcher:
         sys.exit(self_launch(args))
@@ -277,6 +310,7 @@ def main():
     na, nb, ka, kb, E = args.na, args.nb, args.ka, args.kb, args.edges
     n = na + nb
     rowptr, col, planted = make_graph(args, pkg, syn)
+    E = args.edges  # (an --edgelist run: the file's edge count)
     reorder = None
     if args.shuffle_ids and not args.no_reorder and hasattr(pkg, "locality_order"):
         # ingest-time reordering pass for ids that carry no structure: the engine runs on the
@@ -312,11 +346,11 @@ def main():
     def note(what):
         if verbose:
             print("%s launch %.1f ms, accepted %.4f, ended at %.3f" % (
-                what, model.last_sweep_timing()[0], float(model.last_counts()[0].sum()) / (n * shard.n_local),
+                what, model.last_sweep_timing()[0], float(model.last_counts()[0].sum()) / (n * args.sweeps_per_step * shard.n_local),
                 time.time()), file=sys.stderr, flush=True)
 
-    def sweep():
-        mh.anneal(model, pkg.constant_schedule, [1.0], n, 1 << 60)  # blocks until the sweep kernel is done
+    def sweep():  # one timed step: --sweeps-per-step sweeps of every chain in one launch
+        mh.anneal(model, pkg.constant_schedule, [1.0], n * args.sweeps_per_step, 1 << 60)  # blocks until the sweep kernel is done
 
     spin_ms = []
     while args.spinup and len(spin_ms) < args.spinup + 6:
@@ -339,7 +373,7 @@ def main():
         updates += upd
     sync()
     elapsed = time.perf_counter() - t0
-    accepted_frac = float(model.last_counts()[0].sum()) / (n * shard.n_local)
+    accepted_frac = float(model.last_counts()[0].sum()) / (n * args.sweeps_per_step * shard.n_local)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -395,7 +429,7 @@ def main():
             ems += ms
             eupd += upd
         equil = {"updates_per_s_per_gpu": eupd / (ems / 1e3), "avg_launch_ms": ems / 3,
-                 "accepted_fraction": float(model.last_counts()[0].sum()) / (n * shard.n_local),
+                 "accepted_fraction": float(model.last_counts()[0].sum()) / (n * args.sweeps_per_step * shard.n_local),
                  "what": "same graph and chains, started on the planted partition (near the posterior mode), 3 sweeps "
                          "to settle, 3 timed (kernel time)"}
 
@@ -405,7 +439,7 @@ def main():
         balg = b_alg_per_update(n, E)
         achieved = balg * per_launch_updates / avg_kernel_s / 1e9
         default_cfg = ((na, nb, E, ka, kb, args.chains) == (500_000, 500_000, 10_000_000, 32, 32, 1024) and not args.shuffle_ids
-                       and not args.planted_start)
+                       and not args.planted_start and not args.edgelist and args.sweeps_per_step == 1)
         # HBM bytes per launch and instructions per update from the PMC passes committed under profiles/ (rocprofv3
         # --pmc, separate runs of this same command); only quoted for the workload they were measured on
         traffic, traffic_src, issue, steady = None, None, None, None
@@ -449,16 +483,18 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" if not args.edgelist else "edge list file (the reference's shipped data set)" if args.preset else "edge list file",
             "sweeps_per_s": total_updates / elapsed / n,
             "config": {
-                "workload": ("BASELINE configs[2]: " if default_cfg else "custom: ")
-                + "planted bipartite N_a=%d N_b=%d E=%d Ka=%d Kb=%d, %d chains/GPU, constant T=1, eps=1, "
+                "workload": ("BASELINE configs[2]: " if default_cfg else (args.preset + ": ") if args.preset else "custom: ")
+                + ("edge list %s, " % os.path.basename(args.edgelist) if args.edgelist else "planted bipartite ")
+                + "N_a=%d N_b=%d E=%d Ka=%d Kb=%d, %d chains/GPU, constant T=1, eps=1, "
                   "%s start, Philox mode%s" % (na, nb, E, ka, kb, args.chains, "planted-partition" if args.planted_start else "randomised",
                                                        (", node ids renumbered at random" +
                                                         (", locality reordering at ingest (%.1f s)" % reorder_s if reorder else ""))
                                                        if args.shuffle_ids else ""),
-                "chains_total": args.chains * world, "step": "one sweep (n node updates) of every chain",
+                "chains_total": args.chains * world, "step": ("one sweep (n node updates) of every chain" if args.sweeps_per_step == 1
+                                                          else "%d sweeps (of n node updates) of every chain in one launch" % args.sweeps_per_step),
                 "spinup_sweeps_before_warmup": len(spin_ms),
                 "accepted_fraction_last_timed_sweep": accepted_frac,
                 "parallelism": "chains sharded, no collective in the sweep path",
@@ -471,7 +507,7 @@ def main():
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             del model
-            out["cpu_baseline"] = cpu_baseline(n)
+            out["cpu_baseline"] = cpu_baseline(n, probe=REF_PROBE_N1000 if args.preset == "BASELINE configs[1]" else None)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
