@@ -44,6 +44,9 @@ CASES = [
     # K = 32 + 32 with a hub of degree 600: eta (64 x 601 words) does not fit the LDS budget and stays in HBM while the
     # K <= 32 kernel evaluates two steps per pass
     ("k32_eta_in_hbm", 3000, 3000, 60000, 32, 32, 1.0, 1, 0),
+    # the same for the four- and eight-steps-per-pass variants (both block counts <= 16, <= 8)
+    ("k16_eta_in_hbm", 3000, 3000, 60000, 16, 13, 1.0, 1, 0),
+    ("k8_eta_in_hbm", 3000, 3000, 60000, 8, 7, 1.0, 1, 0),
     # epsilon = 0 (legal in the reference: -E 0): no uniform component in the proposal, denominators m_r[t] alone
     ("eps0", 300, 200, 3000, 5, 7, 0.0, 0, 4),
     ("eps0_direct", 20000, 20000, 100000, 2, 2, 0.0, 0, 0),
