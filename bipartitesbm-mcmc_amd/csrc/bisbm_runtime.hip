@@ -219,6 +219,9 @@ struct bisbm_engine {
     // last sweep timing
     double last_kernel_ms = 0;
     uint64_t last_updates = 0;
+    // production kernel, both block counts <= 16: depth of the next launch's passes (1 / 2 / 3 = two / four / eight steps per
+    // pass), from the failure rate of the launch before (ChainScalars::pass_try / pass_fail)
+    uint32_t pass_depth = 3;
     // Chains with different block counts (after a one-argument agg_merge, blockmodel.cc:208-271: every run ends where it
     // ends).  Kernels are launched for one (KA, KB), so the handle then becomes a CONTAINER: its chains live in
     // sub-engines, one per distinct shape (`groups`), which borrow the graph and the tables from it (`root`); chain c of
@@ -733,24 +736,69 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
             p.simd_claims = h->d_simd_claims;
         }
     }
-    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    if (fast)
-        HIPCHK(h, launch_sweep_fast(p, lds, h->stream));
-    else
-        HIPCHK(h, launch_sweep(p, h->rng_mode, lds, h->stream));
-    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    float ms = 0;
-    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    h->last_kernel_ms = ms;
-
+    // One launch, or -- production kernel, few blocks, constant temperature, no early stop in reach (nothing but the sweep
+    // counter and the sums carries over between sweeps then, and both live in the chain's scalars) -- a few launches of whole
+    // sweeps: after each the failure rate of its passes decides how deep the next launch's passes are.  The chain is the same
+    // chain either way (same Philox counters); a run that starts in its burn-in (most steps move: short passes pay) and
+    // ends in equilibrium (long ones do) gets both.
+    const uint64_t total_sweeps = duration_steps / h->n;
+    const bool few_blocks = fast && h->ka <= 16 && h->kb <= 16 && p.pair_steps > 1u;
+    const bool segmented = few_blocks && schedule == SCHED_CONSTANT && (kwargs[0] >= 1.f || steps_await > duration_steps) &&
+                           kwargs[0] > 0.f && total_sweeps >= 2;
     std::vector<ChainScalars> sc(h->n_chains);
-    HIPCHK(h, hipMemcpy(sc.data(), h->d_scalars, sizeof(ChainScalars) * h->n_chains, hipMemcpyDeviceToHost));
-    uint64_t updates = 0;
-    for (uint32_t c = 0; c < h->n_chains; ++c) {
-        if (acc_rate_out) acc_rate_out[c] = sc[c].last_rate;
-        updates += sc[c].last_sweeps * h->n;
+    std::vector<uint64_t> acc_sum(h->n_chains, 0), sweeps_sum(h->n_chains, 0);
+    double ms_sum = 0;
+    uint64_t updates = 0, sweeps_left = segmented ? total_sweeps : 0;
+    // (first segment: at least 10^5 steps per chain, so that a launch lasts tens of milliseconds; then doubling)
+    uint64_t seg = std::max<uint64_t>(1, (100000 + h->n - 1) / h->n);
+    bool first = true;
+    while (first || sweeps_left > 0) {
+        first = false;
+        if (segmented) {
+            const uint64_t now = std::min(seg, sweeps_left);
+            p.duration = now * h->n;
+            sweeps_left -= now;
+            seg *= 2;
+        }
+        p.pass_depth = h->pass_depth;
+        HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+        if (fast)
+            HIPCHK(h, launch_sweep_fast(p, lds, h->stream));
+        else
+            HIPCHK(h, launch_sweep(p, h->rng_mode, lds, h->stream));
+        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        float ms = 0;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        ms_sum += ms;
+        HIPCHK(h, hipMemcpy(sc.data(), h->d_scalars, sizeof(ChainScalars) * h->n_chains, hipMemcpyDeviceToHost));
+        uint64_t tries = 0, fails = 0;
+        for (uint32_t c = 0; c < h->n_chains; ++c) {
+            acc_sum[c] += sc[c].last_accepted;
+            sweeps_sum[c] += sc[c].last_sweeps;
+            updates += sc[c].last_sweeps * h->n;
+            tries += sc[c].pass_try;
+            fails += sc[c].pass_fail;
+        }
+        if (few_blocks && tries >= 64) {
+            // expected commits of a pass of depth d at failure rate f: (1 - (1-f)^d) / f; measured pass costs 0.75 : 0.94 : 1.18
+            // (two : four : eight steps) => eight steps per pass pay below f = 0.29, four below 0.50
+            const double f = (double)fails / (double)tries;
+            h->pass_depth = f < 0.29 ? 3u : f < 0.50 ? 2u : 1u;
+        }
     }
+    const float ms = (float)ms_sum;
+    h->last_kernel_ms = ms_sum;
+    if (segmented) {  // the call's totals, as one launch would have left them
+        for (uint32_t c = 0; c < h->n_chains; ++c) {
+            sc[c].last_accepted = acc_sum[c];
+            sc[c].last_sweeps = sweeps_sum[c];
+            sc[c].last_rate = (double)acc_sum[c] / (double)duration_steps;  // :100
+        }
+        HIPCHK(h, hipMemcpy(h->d_scalars, sc.data(), sizeof(ChainScalars) * h->n_chains, hipMemcpyHostToDevice));
+    }
+    for (uint32_t c = 0; c < h->n_chains; ++c)
+        if (acc_rate_out) acc_rate_out[c] = sc[c].last_rate;
     h->last_updates = updates;
     // BISBM_PLACEMENT_LOG=1 (diagnostic): how the dispatcher spread the launch over the chip.  A SIMD that hosts
     // the stepping waves of two chains runs both of them slower, and the launch takes as long as its slowest chain.
@@ -1711,6 +1759,7 @@ bisbm_engine* new_group(bisbm_engine* root, uint32_t ka, uint32_t kb, uint32_t c
     g->wide = g->K > 256;
     g->epsilon = root->epsilon, g->rng_mode = root->rng_mode, g->seed = root->seed, g->gen_seed = root->gen_seed;
     g->label_stride = root->label_stride;
+    g->pass_depth = root->pass_depth;
     g->d_rowptr = root->d_rowptr, g->d_col = root->d_col, g->d_lgamma = root->d_lgamma, g->d_logtab = root->d_logtab, g->d_q = root->d_q;
     g->tab = root->tab, g->q_stride = root->q_stride, g->ent_deg = root->ent_deg, g->ent_multi = root->ent_multi;
     const size_t C = count, K = g->K, D = (size_t)g->maxdeg + 1;

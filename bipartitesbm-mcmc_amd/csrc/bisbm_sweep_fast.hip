@@ -113,8 +113,9 @@ constexpr uint32_t kRowCap = 255;     // longest row the feeder walks (a k_v cou
 
 // EL: eta in LDS.  CT: constant schedule.  K32: both block counts <= 32 (five-level scans and sums).  K16 (with K32): both
 // block counts <= 16: four steps per pass in the four 16-lane rows of the wave (step_quad).  K8 (with K16): both <= 8: eight
-// steps per pass in groups of eight lanes (step_oct).
-template <bool EL, bool CT, bool K32, bool K16, bool K8>
+// steps per pass in groups of eight lanes (step_oct).  ST: the two-steps pass counts how often its second step stands (the
+// deeper passes always count): the host picks the depth of the next launch from it.
+template <bool EL, bool CT, bool K32, bool K16, bool K8, bool ST>
 __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p) {
     extern __shared__ __align__(16) uint32_t lds32[];
     const uint32_t chain = blockIdx.x;
@@ -235,12 +236,10 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     // inside the lane-0 region of an accepted step (a vector add under the execution mask, no LDS round trip).
     double cum_l0 = sc->cum_dS;
     unsigned long long acc_l0 = 0;
-    // Depth of the passes (K <= 16 / K <= 8 variants): how often did a step of a pass NOT stand (ad_fail) among the steps
-    // that were tried after a pass's first (ad_try)?  Halved at every chunk: a running estimate of the per-step failure rate
-    // f that follows the chain from its burn-in (nearly every step moves, few blocks: most second steps clash) to
-    // equilibrium.  With pass costs 0.75 : 0.94 : 1.18 (two : four : eight steps, measured) and (1 - (1-f)^d) / f expected
-    // commits, eight steps per pass pay below f = 0.29, four below 0.50, two above.
-    uint32_t ad_fail = 0, ad_try = 0;
+    // How deep should the passes be?  pass_try: steps tried after the first of their pass; pass_fail: those that did not
+    // stand.  Their ratio is the per-step failure rate f the host reads after the launch: from a random start on a large
+    // graph with few blocks nearly every step moves and most followers clash (f ~ 0.5), at equilibrium f is a few percent.
+    uint32_t pass_try = 0, pass_fail = 0;
     // anneal()'s early stop (metropolis_hasting.cc:75-76,85-98): `u`, the number of steps with T < 1 since entropy_ last
     // reached a new minimum, is only looked at when a sweep ends.  Kept as u = (steps with T < 1 so far) - (steps with
     // T < 1 before the step of the last minimum): the first count advances once per chunk, the second (and the minimum
@@ -274,19 +273,13 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
             auto mq_at = [&](uint32_t i_own, uint32_t j_oth) -> uint32_t {
                 return TB ? j_oth * S + i_own : i_own * S + j_oth;
             };
-            // Signs of the scalar terms folded into a step's first leaves (see step_general): a pattern of the lane index mod 8;
-            // every kind of pass keeps it in the first eight lanes of each of ITS steps' lane groups only -- the two-steps pass
-            // in lanes 0..7 and 32..39 (lbp = lane & 31), the four-steps pass in the first half of every row, the eight-steps
-            // pass everywhere, the one-step evaluations (step_general, step) in lanes 0..7.
-            const uint32_t l7 = lane & 7u;
-            const double sign_tail8 = (l7 < 2u || l7 >= 6u) ? -1. : 1.;
-            const double sign_q8 = l7 >= 4u ? 0. : (l7 < 2u ? -1. : 1.);
-            const uint32_t lbp = K32 ? (lane & 31u) : lane;  // the two-steps pass's lane <-> block map
-            const double sign_tail32 = lbp < 8u ? sign_tail8 : 0.;
-            const double sign_q32 = lbp < 8u ? sign_q8 : 0.;
-            // (kernels without the deeper passes: the one-step sums never reach lanes 32..39, the same two registers serve)
-            const double sign_tail1 = K16 ? (lane < 8u ? sign_tail8 : 0.) : sign_tail32;
-            const double sign_q1 = K16 ? (lane < 8u ? sign_q8 : 0.) : sign_q32;
+            const double sign_tail = lb >= 8 ? 0. : ((lb < 2 || lb >= 6) ? -1. : 1.);
+            const double sign_q = lb >= 4 ? 0. : (lb < 2 ? -1. : 1.);
+            // the one-step evaluations (step_general, step) sum lanes 0..31 or 0..63 as ONE step: only its first row carries
+            // the scalar terms (with four copies per wave, K <= 16, lanes 16..23 would add them a second time)
+            // (the other variants: the same registers as sign_tail / sign_q -- their one-step sums never reach a second copy)
+            const double sign_tail1 = K16 ? (lane < 8u ? sign_tail : 0.) : sign_tail;
+            const double sign_q1 = K16 ? (lane < 8u ? sign_q : 0.) : sign_q;
             const int eoff_l = (lane & 7u) < 6 ? 1 : ((lane & 1u) ? 2 : 0);       // eta_r+1, eta_s+1, eta_r, eta_s+2
             const int dq_l = (lane & 2u) ? ((lane & 1u) ? 1 : -1) : 0;            // n_r - 1, n_s + 1 in lanes 2,3 (mod 4)
             const int dsgn_l = dq_l;                                              // -deg, +deg in the same lanes
@@ -297,7 +290,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
             TiledOrder order;
             order.init(phx_draw(p.seed, chain_gid, PHX_SWEEP_KEY, 2 * sweeps_total + (TB ? 1 : 0)), n_own);
             const uint32_t n_chunks = (n_own + kWave - 1) / kWave;
-            const unsigned long long lanes_koth32 = __builtin_amdgcn_ballot_w64(lbp < k_oth);  // both halves in the K <= 32 variants
+            const unsigned long long lanes_koth = __builtin_amdgcn_ballot_w64(lb < k_oth);  // both halves in the K <= 32 variants
             const uint32_t node_other0 = TB ? 0u : na;  // some node of the opposite type: what idle slots of the walk load
 
             // ---- feeder wave: everything of chunk c that does not depend on the chain's block state ----
@@ -768,10 +761,10 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t deg = (uint32_t)((int)degA + __mul24((int)half, (int)degB - (int)degA));
                     const uint32_t r_loc = (uint32_t)((int)r_locA + __mul24((int)half, (int)r_locB - (int)r_locA));
                     const uint32_t t_loc = (uint32_t)((int)t_locA + __mul24((int)half, (int)t_locB - (int)t_locA));
-                    const int k = (int)hist8_cur[qs * kHistStride + lbp];
-                    const uint32_t a_rt = mq_at(r_loc, lbp);
+                    const int k = (int)hist8_cur[qs * kHistStride + lb];
+                    const uint32_t a_rt = mq_at(r_loc, lb);
                     const int32_t m_rt_raw = mq[a_rt];
-                    const int w_piv = mq[mq_at(lbp, t_loc)];
+                    const int w_piv = mq[mq_at(lb, t_loc)];
                     const uint32_t liveA = sflag((uint32_t)readlane(nr_own, r_locA) ^ 1u);  // n_r != 1 (:467-471: a block is never emptied)
                     const uint32_t liveB = smin((uint32_t)readlane(nr_own, r_locB) ^ 1u, pairable);
                     const int32_t kmask = (0 - k) >> 31;
@@ -795,7 +788,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     FSTAMP_STEP(2);
                     if ((selfA & selfB) != 0u) {  // both r == s: nothing changes (:109-112)
                         acc_chunk += (liveA & warmA) + (liveB & warmB);
-                        if (K16) ad_try += pairable;
+                        if constexpr (ST) pass_try += pairable;
                         return 1u + pairable;
                     }
                     // Would step q, if it moves its node, touch what step q + 1 read?  (block sets as bit masks)
@@ -811,7 +804,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
 
                     const uint32_t s_loc = (uint32_t)((int)s_locA + __mul24((int)half, (int)s_locB - (int)s_locA));
                     const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
-                    const uint32_t a_st = mq_at(s_loc, lbp);
+                    const uint32_t a_st = mq_at(s_loc, lb);
                     const int32_t m_st_raw = mq[a_st];
                     const uint32_t e_idx = (own_base + idx_l) * D + deg;
                     const int ee = (int)eta_rd(e_idx);
@@ -862,8 +855,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     }
                     FSTAMP_STEP(5);
                     double d = (L1 + L2) - (L3 + L4);
-                    d = d + tail_lg * sign_tail32;
-                    d = d + lq * sign_q32;
+                    d = d + tail_lg * sign_tail;
+                    d = d + lq * sign_q;
                     const double dS = butterfly_rows32(d);
                     FSTAMP_STEP(6);
                     // accept (:47-61) in the lanes that hold the sums; bit 31 is step q's verdict, bit 63 step q + 1's
@@ -890,9 +883,9 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t chA = flags & yesA;                                  // step q moves its node
                     const uint32_t okA = chA | ((flags >> 1) & 1u);                     // ... counts as accepted
                     const uint32_t stands = pairable & ((chA & (flags >> 4)) ^ 1u);     // step q + 1's evaluation stands
-                    if (K16) {
-                        ad_try += pairable;
-                        ad_fail += pairable ^ stands;
+                    if constexpr (ST) {
+                        pass_try += pairable;
+                        pass_fail += pairable ^ stands;
                     }
                     const uint32_t chB = stands & (flags >> 2) & yesB;
                     const uint32_t okB = chB | (stands & (flags >> 3) & 1u);
@@ -904,12 +897,12 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         const int dS_B_lo = __builtin_amdgcn_readlane(__double2loint(dS), 63), dS_B_hi = __builtin_amdgcn_readlane(__double2hiint(dS), 63);
                         const unsigned long long movers = ((unsigned long long)mB << 32) | mA;
                         wfence();
-                        if (__builtin_amdgcn_inverse_ballot_w64(movers & lanes_koth32)) {  // k == 0: rewrites the same values
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & lanes_koth)) {  // k == 0: rewrites the same values
                             mq[a_rt] = m_rt_raw - k;
                             mq[a_st] = m_st_raw + k;
                         }
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000003000000030ull))  // lanes 4, 5: eta_r - 1, eta_s + 1
-                            eta_wr(e_idx, (uint32_t)(ee + ((int)(lbp & 1u) * 2 - 1)));
+                            eta_wr(e_idx, (uint32_t)(ee + ((int)(lb & 1u) * 2 - 1)));
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000000100000001ull)) labels[v] = (uint8_t)(own_base + s_loc);
                         const int dlA = (int)min(lb ^ r_locA, 1u) - (int)min(lb ^ s_locA, 1u);  // +1 on lane s, -1 on lane r
                         const int dlB = (int)min(lb ^ r_locB, 1u) - (int)min(lb ^ s_locB, 1u);
@@ -937,7 +930,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 // are evaluated lane-parallel (lane 4 i + j: steps i and j) and arrive as one 16-bit word.
                 const uint32_t row = lane >> 4;
                 auto step_quad = [&](auto tm, uint32_t q, uint32_t nst) -> uint32_t {  // nst: steps of this pass that exist (1..4)
-                    const uint32_t lbq = lane & 15u;  // this pass's lane <-> block map (the kernel's register copies may be finer: lb)
                     constexpr bool TM = decltype(tm)::value;
                     const uint32_t qs = q + min(row, nst - 1u);  // (rows past nst repeat the last step; their results are ignored)
                     const int sel = (int)(qs << 2);
@@ -947,10 +939,10 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double u_acc = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(ud_acc)),
                                                           __builtin_amdgcn_ds_bpermute(sel, __double2loint(ud_acc)));
                     const uint32_t deg = pack & 255u, r_loc = (pack >> 8) & 63u, t_loc = pack >> 16;
-                    const int k = (int)hist8_cur[qs * kHistStride + lbq];
-                    const uint32_t a_rt = mq_at(r_loc, lbq);
+                    const int k = (int)hist8_cur[qs * kHistStride + lb];
+                    const uint32_t a_rt = mq_at(r_loc, lb);
                     const int32_t m_rt_raw = mq[a_rt];
-                    const int w_piv = mq[mq_at(lbq, t_loc)];
+                    const int w_piv = mq[mq_at(lb, t_loc)];
                     const int nn_r = __builtin_amdgcn_ds_bpermute((int)(r_loc << 2), nr_own);
                     const int32_t kmask = (0 - k) >> 31;
                     const int32_t m_rt = m_rt_raw & kmask;
@@ -972,7 +964,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const unsigned long long b_selfok = __builtin_amdgcn_ballot_w64(valid && live && self && warm) & kRowRep;
                     if (b_can == 0ull) {  // every step of the pass is an r == s (or a vetoed one): nothing changes (:109-112)
                         acc_chunk += (uint32_t)__builtin_popcountll(b_selfok);
-                        ad_try += nst - 1u;
+                        pass_try += nst - 1u;
                         return nst;
                     }
                     // pairwise: would step i, if it moves its node, touch what step j read?  (lane 4 i + j, any row)
@@ -992,7 +984,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         clash_bits = (uint32_t)__builtin_amdgcn_ballot_w64(clash) & 0xffffu;  // bit 4 i + j
                     }
                     const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
-                    const uint32_t a_st = mq_at(s_loc, lbq);
+                    const uint32_t a_st = mq_at(s_loc, lb);
                     const int32_t m_st_raw = mq[a_st];
                     const uint32_t e_idx = (own_base + idx_l) * D + deg;
                     const int ee = (int)eta_rd(e_idx);
@@ -1038,8 +1030,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         }
                     }
                     double d = (L1 + L2) - (L3 + L4);
-                    d = d + tail_lg * ((lane & 8u) == 0u ? sign_tail8 : 0.);
-                    d = d + lq * ((lane & 8u) == 0u ? sign_q8 : 0.);
+                    d = d + tail_lg * sign_tail;
+                    d = d + lq * sign_q;
                     const double dS = butterfly_rows16(d);
                     // accept (:47-61), per row
                     double invT = invT_const;
@@ -1084,12 +1076,12 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         if (moved & 4u) movers |= 0x0000ffff00000000ull;
                         if (moved & 8u) movers |= 0xffff000000000000ull;
                         wfence();
-                        if (__builtin_amdgcn_inverse_ballot_w64(movers & __builtin_amdgcn_ballot_w64(lbq < k_oth))) {  // k == 0: rewrites the same values
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & lanes_koth)) {  // k == 0: rewrites the same values
                             mq[a_rt] = m_rt_raw - k;
                             mq[a_st] = m_st_raw + k;
                         }
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0030003000300030ull))  // lanes 4, 5 of a row: eta_r - 1, eta_s + 1
-                            eta_wr(e_idx, (uint32_t)(ee + ((int)(lbq & 1u) * 2 - 1)));
+                            eta_wr(e_idx, (uint32_t)(ee + ((int)(lb & 1u) * 2 - 1)));
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0001000100010001ull)) labels[v] = (uint8_t)(own_base + s_loc);
                         // the register copies of m_r / n_r, sum dS (:500) and the early-stop bookkeeping, in step order
 #pragma unroll
@@ -1107,8 +1099,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     }
                     {
                         const uint32_t done = (uint32_t)__builtin_popcount(commit), cut = done < nst ? 1u : 0u;
-                        ad_try += done - 1u + cut;
-                        ad_fail += cut;
+                        pass_try += done - 1u + cut;
+                        pass_fail += cut;
                         return done;
                     }
                 };
@@ -1134,7 +1126,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 // with, and the commit chain tests one byte against the movers so far per step.
                 const uint32_t grp = lane >> 3;
                 auto step_oct = [&](auto tm, uint32_t q, uint32_t nst) -> uint32_t {  // nst: steps of this pass that exist (1..8)
-                    const uint32_t lbo = lane & 7u;  // this pass's lane <-> block map (the kernel's register copies may be finer: lb)
                     constexpr bool TM = decltype(tm)::value;
                     const uint32_t qs = q + min(grp, nst - 1u);
                     const int sel = (int)(qs << 2);
@@ -1144,10 +1135,10 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double u_acc = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(ud_acc)),
                                                           __builtin_amdgcn_ds_bpermute(sel, __double2loint(ud_acc)));
                     const uint32_t deg = pack & 255u, r_loc = (pack >> 8) & 63u, t_loc = pack >> 16;
-                    const int k = (int)hist8_cur[qs * kHistStride + lbo];
-                    const uint32_t a_rt = mq_at(r_loc, lbo);
+                    const int k = (int)hist8_cur[qs * kHistStride + lb];
+                    const uint32_t a_rt = mq_at(r_loc, lb);
                     const int32_t m_rt_raw = mq[a_rt];
-                    const int w_piv = mq[mq_at(lbo, t_loc)];
+                    const int w_piv = mq[mq_at(lb, t_loc)];
                     const int nn_r = __builtin_amdgcn_ds_bpermute((int)(r_loc << 2), nr_own);
                     const int32_t kmask = (0 - k) >> 31;
                     const int32_t m_rt = m_rt_raw & kmask;
@@ -1155,7 +1146,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double L1 = tab_at(tab.lg, (uint32_t)(m_rt + 1));
                     const double L3 = tab_at(tab.lg, (uint32_t)(m_rt + 1) - kk);
                     __asm__ volatile("" ::: "memory");
-                    const int scan = group_inclusive_scan8(w_piv, lbo);  // inverse CDF per group of eight (:627-628)
+                    const int scan = group_inclusive_scan8(w_piv, lb);  // inverse CDF per group of eight (:627-628)
                     const unsigned long long hit = __builtin_amdgcn_ballot_w64((uint32_t)scan > prop);
                     const uint32_t field = (uint32_t)(hit >> (grp << 3)) & 0xffu;
                     const uint32_t s_loc = min((uint32_t)__builtin_ctz(field | 0x100u), last_own);
@@ -1168,7 +1159,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const unsigned long long b_selfok = __builtin_amdgcn_ballot_w64(valid && live && self && warm) & kGrpRep;
                     if (b_can == 0ull) {
                         acc_chunk += (uint32_t)__builtin_popcountll(b_selfok);
-                        ad_try += nst - 1u;
+                        pass_try += nst - 1u;
                         return nst;
                     }
                     unsigned long long clash_bits;  // byte j, bit i: step i (earlier), if it moves, touches what step j read
@@ -1187,7 +1178,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         clash_bits = __builtin_amdgcn_ballot_w64(clash);
                     }
                     const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);
-                    const uint32_t a_st = mq_at(s_loc, lbo);
+                    const uint32_t a_st = mq_at(s_loc, lb);
                     const int32_t m_st_raw = mq[a_st];
                     const uint32_t e_idx = (own_base + idx_l) * D + deg;
                     const int ee = (int)eta_rd(e_idx);
@@ -1233,8 +1224,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         }
                     }
                     double d = (L1 + L2) - (L3 + L4);
-                    d = d + tail_lg * (true ? sign_tail8 : 0.);
-                    d = d + lq * (true ? sign_q8 : 0.);
+                    d = d + tail_lg * sign_tail;
+                    d = d + lq * sign_q;
                     const double dS = butterfly_groups8(d);
                     double invT = invT_const;
                     if (!CT) invT = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(invT_l)),
@@ -1266,12 +1257,12 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         for (uint32_t g = 0; g < 8u; ++g)
                             if ((moved >> g) & 1u) movers |= 0xffull << (8u * g);
                         wfence();
-                        if (__builtin_amdgcn_inverse_ballot_w64(movers & __builtin_amdgcn_ballot_w64(lbo < k_oth))) {
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & lanes_koth)) {
                             mq[a_rt] = m_rt_raw - k;
                             mq[a_st] = m_st_raw + k;
                         }
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x3030303030303030ull))  // lanes 4, 5 of a group: eta_r - 1, eta_s + 1
-                            eta_wr(e_idx, (uint32_t)(ee + ((int)(lbo & 1u) * 2 - 1)));
+                            eta_wr(e_idx, (uint32_t)(ee + ((int)(lb & 1u) * 2 - 1)));
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0101010101010101ull)) labels[v] = (uint8_t)(own_base + s_loc);
 #pragma unroll
                         for (uint32_t g = 0; g < 8u; ++g) {
@@ -1288,8 +1279,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     }
                     {
                         const uint32_t done = (uint32_t)__builtin_popcount(commit), cut = done < nst ? 1u : 0u;
-                        ad_try += done - 1u + cut;
-                        ad_fail += cut;
+                        pass_try += done - 1u + cut;
+                        pass_fail += cut;
                         return done;
                     }
                 };
@@ -1325,25 +1316,12 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     }
                     acc_l0 += (unsigned long long)acc_chunk;
                 };
-                // depth of this chunk's passes from the failure rate seen so far (see ad_fail / ad_try)
-                uint32_t depth = 1u;
-                if (K16) {
-                    depth = (K8 && oct_mode) ? 3u : 2u;
-                    if (ad_try >= 8u) {
-                        if (100u * ad_fail >= 50u * ad_try)
-                            depth = 1u;
-                        else if (100u * ad_fail >= 29u * ad_try)
-                            depth = min(depth, 2u);
-                    }
-                    ad_fail >>= 1;
-                    ad_try >>= 1;
-                }
-                if (K8 && oct_mode && depth == 3u) {
+                if (K8 && oct_mode) {
                     if (track_min != 0u)
                         oct_loop(std::true_type{});
                     else
                         oct_loop(std::false_type{});
-                } else if (K16 && (quad_mode || oct_mode) && depth >= 2u) {
+                } else if (K16 && quad_mode) {
                     if (track_min != 0u)
                         quad_loop(std::true_type{});
                     else
@@ -1422,6 +1400,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
         sc->last_rate = rate;
         sc->last_accepted = acc_l0;
         sc->last_sweeps = sweeps_done;
+        sc->pass_try = pass_try;
+        sc->pass_fail = pass_fail;
         // give the SIMD back: workgroups of a later round (more chains than the chip holds at once) claim afresh
         if (p.simd_claims != nullptr) atomicSub(&p.simd_claims[role[wave_in_wg]], 1u);
     }
@@ -1437,21 +1417,25 @@ size_t sweep_fast_lds_bytes(uint32_t ka, uint32_t kb, uint32_t maxdeg, bool eta_
     return ((dwords > reach ? dwords : reach) * 4 + 15) & ~(size_t)15;
 }
 
-template <bool EL, bool CT, bool K32, bool K16, bool K8>
+template <bool EL, bool CT, bool K32, bool K16, bool K8, bool ST>
 static hipError_t launch_fast_variant3(const SweepParams& p, size_t lds_bytes, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)sweep_fast_kernel<EL, CT, K32, K16, K8>,
+    hipError_t e = hipFuncSetAttribute((const void*)sweep_fast_kernel<EL, CT, K32, K16, K8, ST>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((sweep_fast_kernel<EL, CT, K32, K16, K8>), dim3(p.n_chains), dim3(2 * kWave), lds_bytes, stream, p);
+    hipLaunchKernelGGL((sweep_fast_kernel<EL, CT, K32, K16, K8, ST>), dim3(p.n_chains), dim3(2 * kWave), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
+// One kernel per kind of pass (a kernel that held all of them ran out of registers): p.pass_depth, set by the host from the
+// failure rate of the previous launch, says which one a launch with few blocks takes.
 template <bool EL, bool CT>
 static hipError_t launch_fast_variant(const SweepParams& p, size_t lds_bytes, hipStream_t stream) {
-    if (p.ka <= 8u && p.kb <= 8u && p.pair_steps > 2u) return launch_fast_variant3<EL, CT, true, true, true>(p, lds_bytes, stream);
-    if (p.ka <= 16u && p.kb <= 16u && p.pair_steps > 1u) return launch_fast_variant3<EL, CT, true, true, false>(p, lds_bytes, stream);
-    return (p.ka <= 32u && p.kb <= 32u) ? launch_fast_variant3<EL, CT, true, false, false>(p, lds_bytes, stream)
-                                        : launch_fast_variant3<EL, CT, false, false, false>(p, lds_bytes, stream);
+    const uint32_t depth = p.pair_steps < p.pass_depth ? p.pair_steps : p.pass_depth;  // 0 / 1 / 2 / 3: one, two, four, eight steps per pass
+    if (p.ka <= 8u && p.kb <= 8u && depth >= 3u) return launch_fast_variant3<EL, CT, true, true, true, true>(p, lds_bytes, stream);
+    if (p.ka <= 16u && p.kb <= 16u && depth >= 2u) return launch_fast_variant3<EL, CT, true, true, false, true>(p, lds_bytes, stream);
+    if (p.ka <= 16u && p.kb <= 16u) return launch_fast_variant3<EL, CT, true, false, false, true>(p, lds_bytes, stream);  // (counts, so that the depth can go up again)
+    return (p.ka <= 32u && p.kb <= 32u) ? launch_fast_variant3<EL, CT, true, false, false, false>(p, lds_bytes, stream)
+                                        : launch_fast_variant3<EL, CT, false, false, false, false>(p, lds_bytes, stream);
 }
 
 hipError_t launch_sweep_fast(const SweepParams& p, size_t /*generic_lds_bytes*/, hipStream_t stream) {
