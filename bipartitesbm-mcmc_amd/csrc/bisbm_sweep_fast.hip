@@ -1326,7 +1326,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         quad_loop(std::true_type{});
                     else
                         quad_loop(std::false_type{});
-                } else if (K32 && pair_mode) {
+                } else if (K32 && !K16 && pair_mode) {  // (the K <= 16 / K <= 8 kernels hold their own kind of pass only: registers)
                     if (track_min != 0u)
                         pair_loop(std::true_type{});
                     else
