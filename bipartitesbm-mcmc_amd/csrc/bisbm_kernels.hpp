@@ -26,8 +26,6 @@ struct ChainScalars {
     uint32_t hw_id[2];
     uint32_t xcc_id;
     uint32_t split_epoch;  // Philox counter: agg_split calls so far
-    // production kernel, last launch: steps tried after the first of their pass / those that did not stand (see pass_depth)
-    uint32_t pass_try, pass_fail;
 };
 
 struct SweepParams {
@@ -73,7 +71,7 @@ struct SweepParams {
     // 2 = also four per pass where both are <= 16; 3 = also eight per pass where both are <= 8
     uint32_t pair_steps;
     // depth of this launch's passes where the block counts allow a choice (1 / 2 / 3 = two / four / eight steps per pass): the
-    // host sets it from pass_try / pass_fail of the previous launch
+    // host sets it from the measured speed of the launches before (bisbm_anneal)
     uint32_t pass_depth;
     // wide mode (KA + KB > 256; generic kernel only): `labels` holds two-byte labels (label_stride counts labels, not
     // bytes), and the a x b quadrant of m is read and updated in HBM

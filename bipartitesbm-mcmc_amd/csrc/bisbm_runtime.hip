@@ -219,9 +219,11 @@ struct bisbm_engine {
     // last sweep timing
     double last_kernel_ms = 0;
     uint64_t last_updates = 0;
-    // production kernel, both block counts <= 16: depth of the next launch's passes (1 / 2 / 3 = two / four / eight steps per
-    // pass), from the failure rate of the launch before (ChainScalars::pass_try / pass_fail)
-    uint32_t pass_depth = 3;
+    // production kernel, both block counts <= 16: which depth of pass (1 / 2 / 3 = two / four / eight steps) runs how fast
+    // HERE (updates per ms of the launches so far, 0 = not tried yet), and how many launches ago another one was tried
+    double pass_speed[4] = {0, 0, 0, 0};
+    uint32_t pass_launches = 0;
+    bool pass_up = false;
     // Chains with different block counts (after a one-argument agg_merge, blockmodel.cc:208-271: every run ends where it
     // ends).  Kernels are launched for one (KA, KB), so the handle then becomes a CONTAINER: its chains live in
     // sub-engines, one per distinct shape (`groups`), which borrow the graph and the tables from it (`root`); chain c of
@@ -737,30 +739,50 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
         }
     }
     // One launch, or -- production kernel, few blocks, constant temperature, no early stop in reach (nothing but the sweep
-    // counter and the sums carries over between sweeps then, and both live in the chain's scalars) -- a few launches of whole
-    // sweeps: after each the failure rate of its passes decides how deep the next launch's passes are.  The chain is the same
-    // chain either way (same Philox counters); a run that starts in its burn-in (most steps move: short passes pay) and
-    // ends in equilibrium (long ones do) gets both.
+    // counter and the sums carries over between sweeps then, and both live in the chain's scalars) -- several launches of whole
+    // sweeps.  Deep passes (four / eight steps) pay where few steps move or the blocks are many enough for movers to miss each
+    // other (2.4 x on the reference's n_1000 data set); from a random start on a large graph with few blocks nearly every step
+    // moves, most followers clash, and two steps per pass are faster.  Which is which depends on the graph, the partition and
+    // where the chain is, so it is MEASURED: every launch is timed, the depth with the best updates per ms so far runs, and
+    // every eighth launch tries a neighbouring depth again (a chain leaves its burn-in).  The chain is the same chain whatever
+    // runs (same Philox counters, bit-equal results).
     const uint64_t total_sweeps = duration_steps / h->n;
-    const bool few_blocks = fast && h->ka <= 16 && h->kb <= 16 && p.pair_steps > 1u;
-    const bool segmented = few_blocks && schedule == SCHED_CONSTANT && (kwargs[0] >= 1.f || steps_await > duration_steps) &&
+    const uint32_t max_depth = (!fast || p.pair_steps < 2u || h->ka > 16 || h->kb > 16) ? 0u
+                               : std::min<uint32_t>(p.pair_steps, (h->ka <= 8 && h->kb <= 8) ? 3u : 2u);
+    const bool segmented = max_depth >= 2u && schedule == SCHED_CONSTANT && (kwargs[0] >= 1.f || steps_await > duration_steps) &&
                            kwargs[0] > 0.f && total_sweeps >= 2;
     std::vector<ChainScalars> sc(h->n_chains);
     std::vector<uint64_t> acc_sum(h->n_chains, 0), sweeps_sum(h->n_chains, 0);
     double ms_sum = 0;
     uint64_t updates = 0, sweeps_left = segmented ? total_sweeps : 0;
-    // (first segment: at least 10^5 steps per chain, so that a launch lasts tens of milliseconds; then doubling)
-    uint64_t seg = std::max<uint64_t>(1, (100000 + h->n - 1) / h->n);
+    const uint64_t seg = std::max<uint64_t>(1, (100000 + h->n - 1) / h->n);  // >= 10^5 steps per chain and launch: tens of ms
     bool first = true;
     while (first || sweeps_left > 0) {
         first = false;
         if (segmented) {
-            const uint64_t now = std::min(seg, sweeps_left);
+            const uint64_t now = sweeps_left < 2 * seg ? sweeps_left : seg;
             p.duration = now * h->n;
             sweeps_left -= now;
-            seg *= 2;
         }
-        p.pass_depth = h->pass_depth;
+        uint32_t depth = max_depth;
+        if (max_depth >= 2u) {
+            uint32_t best = 0;
+            for (uint32_t d = 1; d <= max_depth; ++d)
+                if (h->pass_speed[d] > h->pass_speed[best] || best == 0) best = h->pass_speed[d] > 0 ? d : best;
+            for (uint32_t d = max_depth; d >= 1; --d)
+                if (h->pass_speed[d] == 0) best = d;  // (not tried yet: shallowest untried first -- it is never far off)
+            depth = best ? best : max_depth;
+            bool all_tried = true;
+            for (uint32_t d = 1; d <= max_depth; ++d) all_tried = all_tried && h->pass_speed[d] > 0;
+            if (all_tried && ++h->pass_launches >= 8u) {  // look again at a neighbour of the best
+                h->pass_launches = 0;
+                h->pass_up = !h->pass_up;  // (one side, then the other)
+                depth = (h->pass_up && best < max_depth) || best == 1u ? best + 1 : best - 1;
+            }
+            if (const char* pd = getenv("BISBM_PASS_DEPTH"))  // diagnostic: 2 / 4 / 8 pins the depth of the passes
+                depth = pd[0] == '2' ? 1u : pd[0] == '4' ? std::min(2u, max_depth) : pd[0] == '8' ? max_depth : depth;
+        }
+        p.pass_depth = depth;
         HIPCHK(h, hipEventRecord(h->ev0, h->stream));
         if (fast)
             HIPCHK(h, launch_sweep_fast(p, lds, h->stream));
@@ -772,19 +794,19 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
         ms_sum += ms;
         HIPCHK(h, hipMemcpy(sc.data(), h->d_scalars, sizeof(ChainScalars) * h->n_chains, hipMemcpyDeviceToHost));
-        uint64_t tries = 0, fails = 0;
+        uint64_t upd = 0;
         for (uint32_t c = 0; c < h->n_chains; ++c) {
             acc_sum[c] += sc[c].last_accepted;
             sweeps_sum[c] += sc[c].last_sweeps;
-            updates += sc[c].last_sweeps * h->n;
-            tries += sc[c].pass_try;
-            fails += sc[c].pass_fail;
+            upd += sc[c].last_sweeps * h->n;
         }
-        if (few_blocks && tries >= 64) {
-            // expected commits of a pass of depth d at failure rate f: (1 - (1-f)^d) / f; measured pass costs 0.75 : 0.94 : 1.18
-            // (two : four : eight steps) => eight steps per pass pay below f = 0.29, four below 0.50
-            const double f = (double)fails / (double)tries;
-            h->pass_depth = f < 0.29 ? 3u : f < 0.50 ? 2u : 1u;
+        updates += upd;
+        if (max_depth >= 2u && ms > 0.05f && upd > 0) {
+            const double speed = (double)upd / ms;
+            h->pass_speed[depth] = h->pass_speed[depth] > 0 ? 0.5 * (h->pass_speed[depth] + speed) : speed;
+            if (getenv("BISBM_PASS_LOG"))
+                fprintf(stderr, "[bisbm passes] depth %u: %.3e updates/ms (two %.3e, four %.3e, eight %.3e)\n", depth, speed, h->pass_speed[1],
+                        h->pass_speed[2], h->pass_speed[3]);
         }
     }
     const float ms = (float)ms_sum;
@@ -1759,7 +1781,7 @@ bisbm_engine* new_group(bisbm_engine* root, uint32_t ka, uint32_t kb, uint32_t c
     g->wide = g->K > 256;
     g->epsilon = root->epsilon, g->rng_mode = root->rng_mode, g->seed = root->seed, g->gen_seed = root->gen_seed;
     g->label_stride = root->label_stride;
-    g->pass_depth = root->pass_depth;
+    for (int d = 0; d < 4; ++d) g->pass_speed[d] = 0;  // (another shape: measured afresh)
     g->d_rowptr = root->d_rowptr, g->d_col = root->d_col, g->d_lgamma = root->d_lgamma, g->d_logtab = root->d_logtab, g->d_q = root->d_q;
     g->tab = root->tab, g->q_stride = root->q_stride, g->ent_deg = root->ent_deg, g->ent_multi = root->ent_multi;
     const size_t C = count, K = g->K, D = (size_t)g->maxdeg + 1;

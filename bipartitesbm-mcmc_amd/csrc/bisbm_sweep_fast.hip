@@ -113,9 +113,8 @@ constexpr uint32_t kRowCap = 255;     // longest row the feeder walks (a k_v cou
 
 // EL: eta in LDS.  CT: constant schedule.  K32: both block counts <= 32 (five-level scans and sums).  K16 (with K32): both
 // block counts <= 16: four steps per pass in the four 16-lane rows of the wave (step_quad).  K8 (with K16): both <= 8: eight
-// steps per pass in groups of eight lanes (step_oct).  ST: the two-steps pass counts how often its second step stands (the
-// deeper passes always count): the host picks the depth of the next launch from it.
-template <bool EL, bool CT, bool K32, bool K16, bool K8, bool ST>
+// steps per pass in groups of eight lanes (step_oct).
+template <bool EL, bool CT, bool K32, bool K16, bool K8>
 __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p) {
     extern __shared__ __align__(16) uint32_t lds32[];
     const uint32_t chain = blockIdx.x;
@@ -236,10 +235,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     // inside the lane-0 region of an accepted step (a vector add under the execution mask, no LDS round trip).
     double cum_l0 = sc->cum_dS;
     unsigned long long acc_l0 = 0;
-    // How deep should the passes be?  pass_try: steps tried after the first of their pass; pass_fail: those that did not
-    // stand.  Their ratio is the per-step failure rate f the host reads after the launch: from a random start on a large
-    // graph with few blocks nearly every step moves and most followers clash (f ~ 0.5), at equilibrium f is a few percent.
-    uint32_t pass_try = 0, pass_fail = 0;
     // anneal()'s early stop (metropolis_hasting.cc:75-76,85-98): `u`, the number of steps with T < 1 since entropy_ last
     // reached a new minimum, is only looked at when a sweep ends.  Kept as u = (steps with T < 1 so far) - (steps with
     // T < 1 before the step of the last minimum): the first count advances once per chunk, the second (and the minimum
@@ -788,7 +783,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     FSTAMP_STEP(2);
                     if ((selfA & selfB) != 0u) {  // both r == s: nothing changes (:109-112)
                         acc_chunk += (liveA & warmA) + (liveB & warmB);
-                        if constexpr (ST) pass_try += pairable;
                         return 1u + pairable;
                     }
                     // Would step q, if it moves its node, touch what step q + 1 read?  (block sets as bit masks)
@@ -883,10 +877,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t chA = flags & yesA;                                  // step q moves its node
                     const uint32_t okA = chA | ((flags >> 1) & 1u);                     // ... counts as accepted
                     const uint32_t stands = pairable & ((chA & (flags >> 4)) ^ 1u);     // step q + 1's evaluation stands
-                    if constexpr (ST) {
-                        pass_try += pairable;
-                        pass_fail += pairable ^ stands;
-                    }
                     const uint32_t chB = stands & (flags >> 2) & yesB;
                     const uint32_t okB = chB | (stands & (flags >> 3) & 1u);
                     acc_chunk += okA + okB;
@@ -964,7 +954,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const unsigned long long b_selfok = __builtin_amdgcn_ballot_w64(valid && live && self && warm) & kRowRep;
                     if (b_can == 0ull) {  // every step of the pass is an r == s (or a vetoed one): nothing changes (:109-112)
                         acc_chunk += (uint32_t)__builtin_popcountll(b_selfok);
-                        pass_try += nst - 1u;
                         return nst;
                     }
                     // pairwise: would step i, if it moves its node, touch what step j read?  (lane 4 i + j, any row)
@@ -1097,12 +1086,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         }
                         wfence();
                     }
-                    {
-                        const uint32_t done = (uint32_t)__builtin_popcount(commit), cut = done < nst ? 1u : 0u;
-                        pass_try += done - 1u + cut;
-                        pass_fail += cut;
-                        return done;
-                    }
+                    return (uint32_t)__builtin_popcount(commit);
                 };
                 auto quad_loop = [&](auto tm) {
                     const unsigned long long gen_mask = __builtin_amdgcn_ballot_w64((int32_t)prop_l < 0);
@@ -1159,7 +1143,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const unsigned long long b_selfok = __builtin_amdgcn_ballot_w64(valid && live && self && warm) & kGrpRep;
                     if (b_can == 0ull) {
                         acc_chunk += (uint32_t)__builtin_popcountll(b_selfok);
-                        pass_try += nst - 1u;
                         return nst;
                     }
                     unsigned long long clash_bits;  // byte j, bit i: step i (earlier), if it moves, touches what step j read
@@ -1277,12 +1260,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         }
                         wfence();
                     }
-                    {
-                        const uint32_t done = (uint32_t)__builtin_popcount(commit), cut = done < nst ? 1u : 0u;
-                        pass_try += done - 1u + cut;
-                        pass_fail += cut;
-                        return done;
-                    }
+                    return (uint32_t)__builtin_popcount(commit);
                 };
                 auto oct_loop = [&](auto tm) {
                     const unsigned long long gen_mask = __builtin_amdgcn_ballot_w64((int32_t)prop_l < 0);
@@ -1400,8 +1378,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
         sc->last_rate = rate;
         sc->last_accepted = acc_l0;
         sc->last_sweeps = sweeps_done;
-        sc->pass_try = pass_try;
-        sc->pass_fail = pass_fail;
         // give the SIMD back: workgroups of a later round (more chains than the chip holds at once) claim afresh
         if (p.simd_claims != nullptr) atomicSub(&p.simd_claims[role[wave_in_wg]], 1u);
     }
@@ -1417,25 +1393,24 @@ size_t sweep_fast_lds_bytes(uint32_t ka, uint32_t kb, uint32_t maxdeg, bool eta_
     return ((dwords > reach ? dwords : reach) * 4 + 15) & ~(size_t)15;
 }
 
-template <bool EL, bool CT, bool K32, bool K16, bool K8, bool ST>
+template <bool EL, bool CT, bool K32, bool K16, bool K8>
 static hipError_t launch_fast_variant3(const SweepParams& p, size_t lds_bytes, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)sweep_fast_kernel<EL, CT, K32, K16, K8, ST>,
+    hipError_t e = hipFuncSetAttribute((const void*)sweep_fast_kernel<EL, CT, K32, K16, K8>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((sweep_fast_kernel<EL, CT, K32, K16, K8, ST>), dim3(p.n_chains), dim3(2 * kWave), lds_bytes, stream, p);
+    hipLaunchKernelGGL((sweep_fast_kernel<EL, CT, K32, K16, K8>), dim3(p.n_chains), dim3(2 * kWave), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
-// One kernel per kind of pass (a kernel that held all of them ran out of registers): p.pass_depth, set by the host from the
-// failure rate of the previous launch, says which one a launch with few blocks takes.
+// One kernel per kind of pass (a kernel that held all of them ran out of registers): p.pass_depth, set by the host, says
+// which one a launch with few blocks takes.
 template <bool EL, bool CT>
 static hipError_t launch_fast_variant(const SweepParams& p, size_t lds_bytes, hipStream_t stream) {
     const uint32_t depth = p.pair_steps < p.pass_depth ? p.pair_steps : p.pass_depth;  // 0 / 1 / 2 / 3: one, two, four, eight steps per pass
-    if (p.ka <= 8u && p.kb <= 8u && depth >= 3u) return launch_fast_variant3<EL, CT, true, true, true, true>(p, lds_bytes, stream);
-    if (p.ka <= 16u && p.kb <= 16u && depth >= 2u) return launch_fast_variant3<EL, CT, true, true, false, true>(p, lds_bytes, stream);
-    if (p.ka <= 16u && p.kb <= 16u) return launch_fast_variant3<EL, CT, true, false, false, true>(p, lds_bytes, stream);  // (counts, so that the depth can go up again)
-    return (p.ka <= 32u && p.kb <= 32u) ? launch_fast_variant3<EL, CT, true, false, false, false>(p, lds_bytes, stream)
-                                        : launch_fast_variant3<EL, CT, false, false, false, false>(p, lds_bytes, stream);
+    if (p.ka <= 8u && p.kb <= 8u && depth >= 3u) return launch_fast_variant3<EL, CT, true, true, true>(p, lds_bytes, stream);
+    if (p.ka <= 16u && p.kb <= 16u && depth >= 2u) return launch_fast_variant3<EL, CT, true, true, false>(p, lds_bytes, stream);
+    return (p.ka <= 32u && p.kb <= 32u) ? launch_fast_variant3<EL, CT, true, false, false>(p, lds_bytes, stream)
+                                        : launch_fast_variant3<EL, CT, false, false, false>(p, lds_bytes, stream);
 }
 
 hipError_t launch_sweep_fast(const SweepParams& p, size_t /*generic_lds_bytes*/, hipStream_t stream) {
