@@ -744,7 +744,7 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     // other (2.4 x on the reference's n_1000 data set); from a random start on a large graph with few blocks nearly every step
     // moves, most followers clash, and two steps per pass are faster.  Which is which depends on the graph, the partition and
     // where the chain is, so it is MEASURED: every launch is timed, the depth with the best updates per ms so far runs, and
-    // every eighth launch tries a neighbouring depth again (a chain leaves its burn-in).  The chain is the same chain whatever
+    // every sixteenth launch tries a neighbouring depth again (a chain leaves its burn-in).  The chain is the same chain whatever
     // runs (same Philox counters, bit-equal results).
     const uint64_t total_sweeps = duration_steps / h->n;
     const uint32_t max_depth = (!fast || p.pair_steps < 2u || h->ka > 16 || h->kb > 16) ? 0u
@@ -769,12 +769,20 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
             uint32_t best = 0;
             for (uint32_t d = 1; d <= max_depth; ++d)
                 if (h->pass_speed[d] > h->pass_speed[best] || best == 0) best = h->pass_speed[d] > 0 ? d : best;
-            for (uint32_t d = max_depth; d >= 1; --d)
-                if (h->pass_speed[d] == 0) best = d;  // (not tried yet: shallowest untried first -- it is never far off)
+            // not tried yet: on small graphs the deepest first (there it won in every regime measured, and a call that cannot
+            // be split -- a cooling schedule, an early stop in reach -- runs its one launch with the first choice); on large ones
+            // the shallowest first (from a random start it is the faster one, and the next launches look further)
+            if (h->n <= 100000) {
+                for (uint32_t d = 1; d <= max_depth; ++d)
+                    if (h->pass_speed[d] == 0) best = d;
+            } else {
+                for (uint32_t d = max_depth; d >= 1; --d)
+                    if (h->pass_speed[d] == 0) best = d;
+            }
             depth = best ? best : max_depth;
             bool all_tried = true;
             for (uint32_t d = 1; d <= max_depth; ++d) all_tried = all_tried && h->pass_speed[d] > 0;
-            if (all_tried && ++h->pass_launches >= 8u) {  // look again at a neighbour of the best
+            if (all_tried && ++h->pass_launches >= 16u) {  // look again at a neighbour of the best
                 h->pass_launches = 0;
                 h->pass_up = !h->pass_up;  // (one side, then the other)
                 depth = (h->pass_up && best < max_depth) || best == 1u ? best + 1 : best - 1;
