@@ -263,6 +263,54 @@ def test_four_and_eight_steps_per_pass_equal_the_serial_chain(monkeypatch):
             assert g.get_entropy()[c] == pytest.approx(o.get_entropy(), rel=1e-9)
 
 
+def test_pass_depth_is_chosen_from_timed_launches_and_never_changes_results(monkeypatch, capfd):
+    """With few blocks the depth of the passes (two / four / eight steps) is chosen per launch from the measured speed of the
+    launches, and a long constant-temperature call runs as several launches so that the choice can follow the chain.  The
+    chain does not depend on any of it: pinned depths and the free choice give bit-equal labels, rates and sums; the log shows
+    that the free run tried every depth."""
+    rowptr, col, na, nb = O.load_graph("n_1000")
+    n = na + nb
+    lab = O.contiguous_labels(na, nb, 4, 6)
+    mh = B.MetropolisHasting()
+    out = {}
+    for pin in ("2", "4", "8", None):
+        if pin is None:
+            monkeypatch.delenv("BISBM_PASS_DEPTH", raising=False)
+            monkeypatch.setenv("BISBM_PASS_LOG", "1")
+        else:
+            monkeypatch.setenv("BISBM_PASS_DEPTH", pin)
+        g = gpu_model(rowptr, col, na, nb, 4, 6, 1.0, lab, n_chains=7, rng="philox", seed=99)
+        g.shuffle_bisbm()
+        capfd.readouterr()
+        rates = [mh.anneal(g, "constant", [1.0], 1234 * n + 77, BIG).copy(),  # (not a whole number of sweeps)
+                 mh.anneal(g, "constant", [0.5], 300 * n, BIG).copy(),        # T < 1, the early stop out of reach
+                 mh.anneal(g, "constant", [0.5], 300 * n, 150 * n).copy(),    # ... in reach: one launch
+                 mh.anneal(g, "exponential", [2.0, 0.99999], 200 * n, BIG).copy()]
+        log = capfd.readouterr().err
+        out[pin] = (rates, [g.get_memberships(c) for c in range(7)], g.get_entropy(), g.last_counts())
+        if pin is None:
+            tried = {int(line.split("depth ")[1][0]) for line in log.splitlines() if line.startswith("[bisbm passes]")}
+            assert tried == {1, 2, 3}, log[-2000:]
+    monkeypatch.delenv("BISBM_PASS_LOG", raising=False)
+    ref = out[None]
+    for pin in ("2", "4", "8"):
+        for a, b in zip(ref[0], out[pin][0]):
+            assert (a == b).all()
+        for a, b in zip(ref[1], out[pin][1]):
+            assert (a == b).all()
+        assert (ref[2] == out[pin][2]).all()
+        assert (ref[3][0] == out[pin][3][0]).all() and (ref[3][1] == out[pin][3][1]).all()
+    o = O.OracleModel(rowptr, col, na, nb, 4, 6, 1.0, lab)
+    o.seed_philox(99, 3)
+    o.shuffle_bisbm()
+    assert o.anneal("constant", [1.0], 1234 * n + 77, BIG) == ref[0][0][3]
+    assert o.anneal("constant", [0.5], 300 * n, BIG) == ref[0][1][3]
+    assert o.anneal("constant", [0.5], 300 * n, 150 * n) == ref[0][2][3]
+    assert o.anneal("exponential", [2.0, 0.99999], 200 * n, BIG) == ref[0][3][3]
+    assert (o.memberships() == ref[1][3]).all()
+    assert (o.last_accepted, o.last_sweeps) == (int(ref[3][0][3]), int(ref[3][1][3]))
+
+
 @pytest.mark.parametrize("roles", ["claims", "1", "2"])
 def test_either_wave_can_step(roles, monkeypatch):
     """The production kernel settles at start which of a workgroup's two waves steps (per-SIMD claims); whichever it is
