@@ -173,6 +173,50 @@ def test_estimate_mode_with_the_one_argument_merge_at_full_size():
     assert updates == chains * n and ms > 0
 
 
+@pytest.mark.parametrize("k", [16, 8])
+def test_deep_passes_at_full_size(k, monkeypatch):
+    """The N = 1e6 / E = 1e7 graph with 16 + 16 and 8 + 8 blocks, 64 chains: the four- and eight-steps passes pinned (the depth
+    is otherwise chosen from timed launches), from the planted partition (few steps move: long passes commit) and from a
+    randomised start (nearly every step moves: passes are cut short all the time).  Sampled chains equal their oracle runs;
+    every chain's incremental state equals a recount and sum dS the change of the description length."""
+    na = nb = 500_000
+    n = na + nb
+    a, b = SYN.planted_edges(na, nb, 10_000_000, k, k, seed=1)
+    rowptr, col = B.edge_to_adj((a, b), n)
+    del a, b
+    planted = SYN.contiguous_labels(na, nb, k, k)
+    chains = 64
+    mh = B.MetropolisHasting()
+    monkeypatch.setenv("BISBM_PASS_DEPTH", "8" if k == 8 else "4")
+    for start in ("planted", "randomised"):
+        g = gpu_model(rowptr, col, na, nb, k, k, 1.0, planted, n_chains=chains, rng="philox", seed=5)
+        oracles = []
+        for c in (0, 63):
+            o = O.OracleModel(rowptr, col, na, nb, k, k, 1.0, planted)
+            o.seed_philox(5, c)
+            oracles.append((c, o))
+        if start == "planted":
+            g.init_bisbm()
+            for _, o in oracles:
+                o.init_bisbm()
+        else:
+            g.shuffle_bisbm()
+            for _, o in oracles:
+                o.shuffle_bisbm()
+        s0, cum0 = g.entropy(), g.get_entropy()
+        rates = mh.anneal(g, "constant", [1.0], 2 * n, BIG)
+        for c, o in oracles:
+            assert o.anneal("constant", [1.0], 2 * n, BIG) == rates[c], (start, c)
+            assert_state_equal(g, o, c)
+        dcum = g.get_entropy() - cum0
+        assert np.allclose(g.entropy() - s0, dcum, rtol=1e-9, atol=1e-6 * max(1.0, np.abs(dcum).max()))
+        state = [(c, g.get_m(c), g.get_m_r(c), g.get_n_r(c), g.get_eta_rk_(c)) for c in range(0, chains, 9)]
+        g.init_bisbm()  # recount from the labels
+        for c, m, m_r, n_r, eta in state:
+            assert (g.get_m(c) == m).all() and (g.get_m_r(c) == m_r).all() and (g.get_n_r(c) == n_r).all()
+            assert (g.get_eta_rk_(c) == eta).all() and n_r.sum() == n and m_r.sum() == 2 * 10_000_000
+
+
 # ------------------------------------------------------------------ BASELINE configs[4]: per-GPU shape
 def test_config5_shape_properties():
     """N_a = N_b = 2e6, E = 5e7, Ka = Kb = 64 (the K > 32 variant of the production kernel, eta in HBM), 16 chains:
