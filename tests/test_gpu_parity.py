@@ -1081,6 +1081,25 @@ def test_cli_marginalize_matches_oracle_replay_and_the_python_driver():
     assert bad.returncode == 1 and "no sample" in bad.stderr
 
 
+def test_examples_run(golden):
+    """examples/: the reference README's walk-through against the re-hosted CLI, and the Python mirror of the class API."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["bash", os.path.join(root, "examples", "maximization.sh")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = golden["compat_rng"]["scenario1_config1"]["labels"]
+    assert r.stdout.split() == [str(x) for x in want]  # the reference's recorded line for these seeds
+    r = subprocess.run(["bash", os.path.join(root, "examples", "marginalization.sh")], capture_output=True, text=True)
+    assert r.returncode == 0 and len(r.stdout.split()) == 1000 and "256 chain(s) pooled" in r.stderr, r.stderr
+    lab = np.array(r.stdout.split(), dtype=int)
+    assert set(lab[:500]) <= set(range(4)) and set(lab[500:]) <= set(range(4, 10))
+    r = subprocess.run(["bash", os.path.join(root, "examples", "estimate_k.sh")], capture_output=True, text=True)
+    assert r.returncode == 0 and len(r.stdout.split()) == 1000 and "(Ka, Kb) = (4, 6) " in r.stderr, r.stderr
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "python_api.py")], capture_output=True, text=True)
+    assert r.returncode == 0 and "blocks now: 4 + 6" in r.stdout, r.stdout + r.stderr
+
+
 # ------------------------------------------------------------------ full size: properties
 def test_full_size_properties():
     """BASELINE configs[2] as benchmarked (N_a=N_b=5e5, E=1e7, Ka=Kb=32, 1024 chains): one sweep keeps the
