@@ -400,6 +400,7 @@ def main():
         # (128 MB of counts at this workload, 1 GB at config 5's)
         dev = torch.device("cuda", device_index)
         counts = torch.zeros((n, model.kmax), dtype=torch.int32, device=dev)
+        torch.cuda.current_stream(dev).synchronize()  # (the zero fill is torch's stream, the histogram kernel the library's)
         model.marginals_accumulate(counts.data_ptr())
         torch.cuda.synchronize()
         send = counts if backend == "nccl" else counts.cpu()

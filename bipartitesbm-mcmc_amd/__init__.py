@@ -46,6 +46,7 @@ _f32p = C.POINTER(C.c_float)
 # every symbol include/bisbm.h and include/bisbm_io.h declare: (restype, argtypes)
 ABI = {
     "bisbm_abi_version": (C.c_int, []),
+    "bisbm_check_shape": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int]),
     "bisbm_last_error": (C.c_char_p, [C.c_void_p]),
     "bisbm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint64, C.c_uint64, C.c_uint64, _u64p, _u32p,
                                C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, C.c_uint32, C.c_int, C.c_int,

@@ -353,11 +353,38 @@ int gather_groups(bisbm_engine* h, T* out, F f) {
     });
 }
 
+// LDS of the generic kernel without the optional parts (eta, the visit list): the a x b quadrant of m (odd row stride; in
+// HBM while wide), m_r, n_r, the k_v histogram, staged rows; compat mode adds two mt19937 states and their tempered outputs.
+// Wide mode (KA + KB > 256) therefore ends where m_r / n_r / the histogram leave the 160 KiB of a CU -- about 11 000 to
+// 18 000 blocks depending on the split and the RNG mode -- well below what two-byte labels could name.
+size_t generic_lds_base_bytes(uint32_t ka, uint32_t kb, bool wide, int rng_mode) {
+    const size_t K = (size_t)ka + kb, S = kb | 1u;
+    size_t lds = sizeof(int32_t) * ((wide ? 0 : (size_t)ka * S) + 2 * K + std::max<uint32_t>(std::max(ka, kb), 64)) + sizeof(uint32_t) * 64 * 64;
+    if (rng_mode == BISBM_RNG_MT19937_COMPAT) lds += sizeof(uint32_t) * 624 * 4;
+    return lds;
+}
+constexpr size_t kLdsPerCu = 160 * 1024;
+
 }  // namespace
 
 extern "C" {
 
 int bisbm_abi_version(void) { return BISBM_ABI_VERSION; }
+
+int bisbm_check_shape(uint32_t ka, uint32_t kb, int rng_mode) {
+    if (ka == 0 || kb == 0) return fail(nullptr, BISBM_ERR_INVALID_ARG, "ka and kb must be >= 1");
+    if (rng_mode != BISBM_RNG_PHILOX && rng_mode != BISBM_RNG_MT19937_COMPAT)
+        return fail(nullptr, BISBM_ERR_INVALID_ARG, "unknown rng_mode %d", rng_mode);
+    if ((uint64_t)ka + kb > 65535) return fail(nullptr, BISBM_ERR_UNSUPPORTED, "ka + kb = %llu > 65535 (labels are at most two bytes)", (unsigned long long)ka + kb);
+    const bool wide = ka + kb > 256;
+    const size_t lds = (generic_lds_base_bytes(ka, kb, wide, rng_mode) + 15) & ~(size_t)15;
+    if (wide && lds > kLdsPerCu)
+        return fail(nullptr, BISBM_ERR_UNSUPPORTED,
+                    "%u + %u blocks: above 256 blocks m_r, n_r and the k_v histogram of a chain stay in LDS and need %zu B here (a CU has %zu); "
+                    "the limit is about %u blocks for an even split in this RNG mode", ka, kb, lds, kLdsPerCu,
+                    (unsigned)((kLdsPerCu - sizeof(uint32_t) * 64 * 64 - (rng_mode == BISBM_RNG_MT19937_COMPAT ? sizeof(uint32_t) * 624 * 4 : 0)) / 10));
+    return BISBM_OK;
+}
 
 const char* bisbm_last_error(bisbm_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -370,6 +397,9 @@ int bisbm_create(bisbm_handle* out, uint64_t n, uint64_t na, uint64_t nb, const 
     if (n == 0 || na + nb != n) return fail(nullptr, BISBM_ERR_INVALID_ARG, "na + nb must equal n > 0");
     if (ka == 0 || kb == 0) return fail(nullptr, BISBM_ERR_INVALID_ARG, "ka and kb must be >= 1");
     if ((uint64_t)ka + kb > 65535) return fail(nullptr, BISBM_ERR_UNSUPPORTED, "ka + kb = %llu > 65535 (labels are at most two bytes)", (unsigned long long)ka + kb);
+    if (rng_mode != BISBM_RNG_PHILOX && rng_mode != BISBM_RNG_MT19937_COMPAT)
+        return fail(nullptr, BISBM_ERR_INVALID_ARG, "unknown rng_mode %d", rng_mode);
+    if (int rc = bisbm_check_shape(ka, kb, rng_mode)) return rc;  // (the LDS plan of wide mode: refuse here, not at the first anneal)
     if (ka > na || kb > nb) return fail(nullptr, BISBM_ERR_INVALID_ARG, "more blocks than nodes of a type (ka %u / na %llu, kb %u / nb %llu)", ka, (unsigned long long)na, kb, (unsigned long long)nb);
     if (n_chains == 0) return fail(nullptr, BISBM_ERR_INVALID_ARG, "n_chains must be >= 1");
     if (rng_mode != BISBM_RNG_PHILOX && rng_mode != BISBM_RNG_MT19937_COMPAT)
@@ -709,7 +739,7 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     } else {
         // generic kernel: m quadrant (odd row stride), m_r, n_r, k_v histogram, staged rows; compat adds the
         // two mt19937 states and (small graphs) the visit list
-        lds = sizeof(int32_t) * ((h->wide ? 0 : h->ka * S) + 2 * K + std::max<uint32_t>(std::max(h->ka, h->kb), 64)) + sizeof(uint32_t) * 64 * 64;
+        lds = generic_lds_base_bytes(h->ka, h->kb, h->wide, BISBM_RNG_PHILOX);
         p.eta_in_lds = (!h->wide && lds + eta_bytes <= 40 * 1024) ? 1 : 0;
         if (p.eta_in_lds) lds += eta_bytes;
         if (h->rng_mode == BISBM_RNG_MT19937_COMPAT) {
@@ -749,8 +779,11 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     const uint64_t total_sweeps = duration_steps / h->n;
     const uint32_t max_depth = (!fast || p.pair_steps < 2u || h->ka > 16 || h->kb > 16) ? 0u
                                : std::min<uint32_t>(p.pair_steps, (h->ka <= 8 && h->kb <= 8) ? 3u : 2u);
-    const bool segmented = max_depth >= 2u && schedule == SCHED_CONSTANT && (kwargs[0] >= 1.f || steps_await > duration_steps) &&
-                           kwargs[0] > 0.f && total_sweeps >= 2;
+    // ("no early stop in reach": at T >= 1 the count u of metropolis_hasting.cc:85-98 stays 0, so the test `u >= steps_await`
+    // after a sweep fires exactly when steps_await == 0 -- then the call ends after its FIRST sweep with rate accepted / N
+    // (:96-98) and must stay one launch; below T = 1 the count gains at most one per step)
+    const bool segmented = max_depth >= 2u && schedule == SCHED_CONSTANT &&
+                           ((kwargs[0] >= 1.f && steps_await > 0) || steps_await > duration_steps) && kwargs[0] > 0.f && total_sweeps >= 2;
     std::vector<ChainScalars> sc(h->n_chains);
     std::vector<uint64_t> acc_sum(h->n_chains, 0), sweeps_sum(h->n_chains, 0);
     double ms_sum = 0;

@@ -8,7 +8,7 @@ sweep kernels run with no collective.  Collectives appear only where chains are 
   * all_gather of per-chain scalars (sum dS / description length, acceptance rate, counts);
   * marginals: every rank histograms its own chains into counts[n, kmax]; the pooled histogram is a
     reduce_scatter over node ranges, the MAP label an argmax on each rank's node range, the full
-    label vector an all_gather of uint8 labels.  On the fully connected xGMI topology
+    label vector an all_gather of uint8 labels (int32 above 256 blocks).  On the fully connected xGMI topology
     a reduce_scatter moves 1/world of the buffer per link concurrently instead of a ring's
     per-link-bound all_reduce.
 
@@ -67,10 +67,11 @@ class ChainShard:
 
     # -- marginals --------------------------------------------------------------------------
     def node_range(self, n, rank=None):
-        """Node rows [lo, hi) of the pooled histogram that `rank` reduces."""
+        """Node rows [lo, hi) of the pooled histogram that `rank` reduces in map_labels (the n % world last rows are
+        summed on every rank)."""
         rank = self.rank if rank is None else rank
-        per = (n + self.world_size - 1) // self.world_size
-        return min(rank * per, n), min((rank + 1) * per, n)
+        per = n // self.world_size
+        return rank * per, (rank + 1) * per
 
     def pooled_marginals(self, local_counts):
         """all_reduce(sum) of counts[n, kmax] (int32): every rank gets the pooled histogram."""
@@ -82,28 +83,38 @@ class ChainShard:
 
     def map_labels(self, local_counts, na, ka):
         """MAP block of every node from the pooled histogram: reduce_scatter by node range, argmax on
-        the owned rows (ties -> lowest block, like numpy), all_gather of uint8 labels.  Returns a uint8
-        tensor [n] of block indices in the reference's numbering (type-b blocks offset by ka)."""
+        the owned rows (ties -> lowest block, like numpy), all_gather of the labels.  Returns a tensor [n] of
+        block indices in the reference's numbering (type-b blocks offset by ka): uint8 while every label fits a
+        byte (ka + kmax <= 256), int32 otherwise (wide handles, two-byte labels inside the library).
+
+        The histogram is handed to reduce_scatter_tensor as it is -- rows [0, world * (n // world)) are a view, not
+        a padded copy (the buffer is 1 GB at BASELINE configs[4]); the fewer than `world` rows that do not divide
+        evenly are summed with one small all_reduce and labelled on every rank."""
         import torch
         dist = _dist()
         n, kmax = local_counts.shape
-        per = (n + self.world_size - 1) // self.world_size
+        lab_dtype = torch.uint8 if int(ka) + int(kmax) <= 256 else torch.int32
+
+        def label_rows(rows, first_node):
+            node = torch.arange(first_node, first_node + rows.shape[0], device=rows.device)
+            return (_argmax_first(rows) + torch.where(node >= na, ka, 0)).to(lab_dtype)
+
         if self.world_size == 1:
-            mine = local_counts
-        else:
-            padded = torch.zeros((per * self.world_size, kmax), dtype=local_counts.dtype, device=local_counts.device)
-            padded[:n] = local_counts
+            return label_rows(local_counts, 0)
+        per = n // self.world_size
+        n_main = per * self.world_size
+        parts = []
+        if per > 0:
             mine = torch.empty((per, kmax), dtype=local_counts.dtype, device=local_counts.device)
-            dist.reduce_scatter_tensor(mine, padded, op=dist.ReduceOp.SUM, group=self.group)
-        lo = self.rank * per if self.world_size > 1 else 0
-        arg = _argmax_first(mine)
-        node = torch.arange(lo, lo + mine.shape[0], device=mine.device)
-        lab = (arg + torch.where(node >= na, ka, 0)).to(torch.uint8)
-        if self.world_size == 1:
-            return lab[:n]
-        out = torch.empty(per * self.world_size, dtype=torch.uint8, device=lab.device)
-        dist.all_gather_into_tensor(out, lab.contiguous(), group=self.group)
-        return out[:n]
+            dist.reduce_scatter_tensor(mine, local_counts[:n_main], op=dist.ReduceOp.SUM, group=self.group)
+            out = torch.empty(n_main, dtype=lab_dtype, device=mine.device)
+            dist.all_gather_into_tensor(out, label_rows(mine, self.rank * per).contiguous(), group=self.group)
+            parts.append(out)
+        if n_main < n:
+            tail = local_counts[n_main:].clone()
+            dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group)
+            parts.append(label_rows(tail, n_main))
+        return torch.cat(parts) if len(parts) > 1 else parts[0]
 
 
 def _argmax_first(counts):

@@ -6,7 +6,7 @@
 // small parser with the same surface (long/short names, `--opt=value`, multitoken options).
 // Extra flags: --chains, --device, --rng {mt19937-compat,philox}, --gen_seed, --csr_cache, --reorder, --marginalize.
 // The agglomerative drivers (:349-451) run through bisbm_agg_merge.  --merge starts at one block per node: while
-// KA + KB > 256 the library runs its wide mode (two-byte labels, generic kernel), up to 65535 blocks.
+// KA + KB > 256 the library runs its wide mode (two-byte labels, generic kernel), up to about 14 000 blocks (bisbm_check_shape).
 // Negative diffs (agg_split) run through the same call (blockmodel.cc:110-117).
 #include <chrono>
 #include <limits>
@@ -440,9 +440,12 @@ int main(int argc, char const* argv[]) {
         return true;
     };
     if (merge) {
-        if (NA + NB > 65535) {  // the start is one block per node (:350-353); block labels are at most two bytes on the device
-            std::cerr << "[error] --merge starts from one block per node (" << NA + NB << " blocks); this engine holds at most 65535 "
-                         "blocks. Start from an initial partition of fewer blocks (-n / --mb / --membership_path with a larger -z "
+        // the start is one block per node (:350-353): ask the library whether it serves that many blocks (its wide mode ends at
+        // about 14 000) before the expensive part starts
+        if (NA + NB > 65535 || bisbm_check_shape((uint32_t)NA, (uint32_t)NB, opt.rng_mode) != BISBM_OK) {
+            std::cerr << "[error] --merge starts from one block per node (" << NA + NB << " blocks): "
+                      << (NA + NB > 65535 ? "block labels are at most two bytes on the device" : bisbm_last_error(nullptr))
+                      << ". Start from an initial partition of fewer blocks (-n / --mb / --membership_path with a larger -z "
                          "than wanted is merged down the same way, mcmc_main.cc:419-450).\n";
             return 3;
         }

@@ -17,20 +17,26 @@ import numpy as np
 
 
 def marginalize(model, burn_in_sweeps, n_samples, sampling_frequency_sweeps, shard=None, device_counts=None,
-                return_counts=True):
+                return_counts=None):
     """Runs the chain(s) of `model` (a BlockModel whose state is already initialised by init_bisbm() /
     shuffle_bisbm()) and returns (labels, counts):
       labels  uint32 [n]         MAP block of every node in the reference's numbering
       counts  [n, max(KA,KB)]    pooled histogram (column = block index within the node's type); None when
-                                 return_counts is False (with several ranks the pooled histogram costs an all_reduce)
+                                 return_counts is False.  Default: returned on a single rank, NOT returned when the chains
+                                 are spread over ranks (there the pooled histogram costs an all_reduce of the whole
+                                 n x kmax buffer, 1 GB at BASELINE configs[4], on top of the reduce_scatter the labels need)
     `shard`: a distributed.ChainShard when chains are spread over ranks.
     `device_counts`: a torch int32 tensor [n, kmax] on the model's device to accumulate into (it is NOT zeroed: samples
     add to what it holds); by default one is allocated when pooling over ranks, and the library's internal buffer is
-    used for a single rank."""
+    used for a single rank.  The library's kernels run on the handle's own (non-blocking) stream, so whatever torch
+    still has in flight on the tensor (its zero fill, a caller's writes) is waited for here before the first sample
+    is added -- the stream contract include/bisbm.h states for `device_counts`."""
     n = model.n
+    multi = shard is not None and shard.world_size > 1
+    if return_counts is None:
+        return_counts = not multi
     if burn_in_sweeps > 0:
         model.run_sweeps(burn_in_sweeps)
-    multi = shard is not None and shard.world_size > 1
     if device_counts is None and not multi:
         # one rank, no caller buffer: the library's own histogram
         model.marginals_reset()
@@ -48,6 +54,11 @@ def marginalize(model, burn_in_sweeps, n_samples, sampling_frequency_sweeps, sha
     if (not isinstance(device_counts, torch.Tensor) or device_counts.dtype != torch.int32
             or tuple(device_counts.shape) != (n, model.kmax) or not device_counts.is_contiguous()):
         raise ValueError("device_counts must be a contiguous torch.int32 tensor of shape (n, max(KA, KB)) on the model's device")
+    if device_counts.is_cuda:
+        # torch.zeros / the caller's kernels ran on torch's stream, bisbm_marginals_accumulate adds with plain (non-atomic)
+        # read-modify-writes on the library's stream: order the two before the first sample.  (The other direction needs
+        # nothing: bisbm_marginals_accumulate returns after its kernel has finished.)
+        torch.cuda.current_stream(device_counts.device).synchronize()
     for _ in range(int(n_samples)):
         if sampling_frequency_sweeps > 0:
             model.run_sweeps(sampling_frequency_sweeps)

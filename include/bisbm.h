@@ -21,8 +21,9 @@
 extern "C" {
 #endif
 
-/* 2: bisbm_get_ka_kb_chain; KA + KB up to 65535 (wide mode); handles whose chains differ in shape.  Additions only. */
-#define BISBM_ABI_VERSION 2
+/* 2: bisbm_get_ka_kb_chain; KA + KB above 256 (wide mode); handles whose chains differ in shape.
+ * 3: bisbm_check_shape; several devices behind one handle (bisbm_create_multi).  Additions only. */
+#define BISBM_ABI_VERSION 3
 
 typedef struct bisbm_engine *bisbm_handle;
 
@@ -30,7 +31,7 @@ typedef enum bisbm_status {
     BISBM_OK = 0,
     BISBM_ERR_INVALID_ARG = 1,   /* null pointer, size mismatch, label out of range ... */
     BISBM_ERR_NOT_BIPARTITE = 2, /* an edge joins two nodes of one type, or an id >= n */
-    BISBM_ERR_UNSUPPORTED = 3,   /* K > 65535 (labels are at most two bytes), more than 2^32-1 adjacency entries ... */
+    BISBM_ERR_UNSUPPORTED = 3,   /* more blocks than wide mode serves (bisbm_check_shape), more than 2^32-1 adjacency entries ... */
     BISBM_ERR_NO_DEVICE = 4,     /* no HIP device / bad ordinal: the engine has no CPU path */
     BISBM_ERR_HIP = 5,           /* a HIP runtime call failed */
     BISBM_ERR_STATE = 6          /* call order (e.g. anneal before init/shuffle) */
@@ -67,7 +68,7 @@ typedef enum bisbm_schedule {
  * of this handle has global id first_chain_id + i (the id keys its random stream, so results do
  * not depend on how chains are sharded over GPUs).  Builds the lgamma / log_q tables
  * (support/cache.cc:64-91, support/int_part.cc:34-51) on the host and uploads them.
- * ka + kb <= 65535 and no more blocks than nodes of a type.  With ka + kb > 256 (the reference's --merge driver starts from one
+ * No more blocks than nodes of a type, and a shape bisbm_check_shape accepts.  With ka + kb > 256 (the reference's --merge driver starts from one
  * block per node, mcmc_main.cc:350-353) the handle runs in WIDE MODE: two-byte labels, the block matrix read and updated in
  * HBM, the generic kernel (slow per step; meant for the greedy sweeps between merge stages); bisbm_agg_merge switches it to
  * byte labels and the ordinary kernels as soon as it leaves ka + kb <= 256.  Splits are refused (BISBM_ERR_UNSUPPORTED)
@@ -78,6 +79,13 @@ int bisbm_create(bisbm_handle *out, uint64_t n, uint64_t na, uint64_t nb, const 
                  uint64_t gen_seed);
 
 int bisbm_destroy(bisbm_handle h);
+
+/* Whether a handle of ka + kb blocks can be served, without creating one (no reference counterpart: blockmodel_t has no
+ * block limit; the CLI's --merge driver asks before it starts from one block per node, mcmc_main.cc:350-353).
+ * Up to 256 blocks: always.  Above (wide mode): labels are two bytes (ka + kb <= 65535) and a chain's m_r, n_r and k_v histogram
+ * stay in LDS, which ends at about 14 000 blocks (even split: 14 700 in Philox mode, 13 700 in mt19937-compat mode; 10 bytes
+ * per block plus 4 for the larger type, 160 KiB per CU).  BISBM_ERR_UNSUPPORTED with the numbers in bisbm_last_error(NULL). */
+int bisbm_check_shape(uint32_t ka, uint32_t kb, int rng_mode);
 
 /* Initial partition: the `memberships` constructor argument (blockmodel.cc:23), n labels in
  * [0, ka+kb).  chain = BISBM_ALL_CHAINS copies the vector to every chain. */
@@ -124,7 +132,11 @@ int bisbm_get_last_counts(bisbm_handle h, uint64_t *accepted, uint64_t *sweeps);
  * mcmc_main.cc:61-65 parses -b/-f and never uses them): add one sample of every chain's labels
  * to counts[n][kmax], kmax = max(ka,kb), column = block index within the node's type.
  * device_counts is a DEVICE pointer to n*kmax uint32 owned by the caller (e.g. a torch tensor
- * that RCCL then reduces across ranks); NULL uses an internal buffer read by bisbm_marginals_get. */
+ * that RCCL then reduces across ranks); NULL uses an internal buffer read by bisbm_marginals_get.
+ * Stream contract: the histogram kernel runs on the handle's own non-blocking stream and adds with
+ * plain read-modify-writes, so everything the caller has in flight on device_counts (its zero fill,
+ * its own kernels) must have COMPLETED before the call (synchronise the stream that wrote it); the
+ * call returns after its kernel has finished, so the caller may read the buffer right away. */
 int bisbm_marginals_accumulate(bisbm_handle h, uint32_t *device_counts);
 int bisbm_marginals_reset(bisbm_handle h);
 int bisbm_marginals_get(bisbm_handle h, uint32_t *counts_out /* n*kmax, host */);

@@ -32,7 +32,26 @@ def test_every_declared_symbol_is_exported_and_bound(built):
     for name in sorted(declared):
         assert hasattr(raw, name), "libbisbm_hip.so does not export %s" % name
     assert declared == set(B.ABI), (declared ^ set(B.ABI))
-    assert built.bisbm_abi_version() == 2
+    assert built.bisbm_abi_version() == 3
+
+
+def test_check_shape_states_the_wide_mode_limit(built):
+    """bisbm_check_shape answers without a device: every shape up to 256 blocks, wide shapes while a chain's m_r / n_r / k_v
+    histogram fit the LDS of a CU (10 bytes per block + 4 for the larger type + 16 KiB, + 9984 B of generator state in
+    mt19937-compat mode), refused with the numbers beyond -- which is what bisbm_create and `mcmc --merge` report up front."""
+    ok = lambda ka, kb, mode: built.bisbm_check_shape(ka, kb, mode)
+    assert ok(1, 1, 0) == 0 and ok(128, 128, 1) == 0 and ok(500, 500, 0) == 0 and ok(7000, 7000, 0) == 0
+    assert ok(7372, 7372, 0) == 0 and ok(7373, 7373, 0) == B.BISBM_ERR_UNSUPPORTED  # 10 K + 16384 <= 163840
+    assert ok(6873, 6873, 1) == 0 and ok(6874, 6874, 1) == B.BISBM_ERR_UNSUPPORTED
+    assert b"LDS" in built.bisbm_last_error(None)
+    assert ok(40000, 30000, 0) == B.BISBM_ERR_UNSUPPORTED and b"two bytes" in built.bisbm_last_error(None)
+    assert ok(0, 3, 0) == B.BISBM_ERR_INVALID_ARG and ok(3, 3, 7) == B.BISBM_ERR_INVALID_ARG
+    # bisbm_create refuses the same shapes before it looks for a device
+    big_n = 20000
+    with pytest.raises(B.BisbmError) as e:
+        B.BlockModel(np.arange(big_n, dtype=np.uint32), np.r_[np.zeros(10000), np.ones(10000)].astype(np.uint32), big_n, 10000, 10000, 1.0,
+                     (np.zeros(big_n + 1, dtype=np.uint64), np.zeros(0, dtype=np.uint32)))
+    assert e.value.code == B.BISBM_ERR_UNSUPPORTED and "LDS" in str(e.value)
 
 
 def test_header_cites_the_reference_interface():
@@ -122,7 +141,8 @@ def test_cli_flag_handling_matches_reference_messages(built):
     rc, out, err = run("-e", el, "--bogus")
     assert rc == 1 and "unrecognised option" in err
     # --merge starts from one block per node: 1000 blocks run in the library's wide mode (two-byte labels), so on a box
-    # without a GPU the run gets as far as bisbm_create; beyond 65535 nodes it is refused with a plain message
+    # without a GPU the run gets as far as bisbm_create; beyond what wide mode serves (bisbm_check_shape) it is refused with a
+    # plain message
     big = os.path.join(ROOT, "tests", "golden", "bisbm-n_1000-ka_4-kb_6.edgelist")
     rc, out, err = run("-e", big, "-y", "500", "500", "-n", "500", "500", "-z", "4", "6", "--merge", "-c", "abrupt_cool", "-a", "50", "-t", "1000")
     assert (rc == 3 and "no HIP device" in err and out == "") or (rc == 0 and len(out.split()) == 1000)

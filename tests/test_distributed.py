@@ -99,6 +99,42 @@ def test_world2_gloo_pooling_equals_single_process(tmp_path):
     assert (mapl == want.argmax(axis=1) + base).all()
 
 
+def _wide_counts(rank, n, na, ka, kb):
+    rs = np.random.default_rng(100 + rank)
+    c = rs.integers(0, 50, size=(n, max(ka, kb))).astype(np.int32)
+    c[:na, ka:] = 0  # (columns past a type's block count stay empty, as the kernel leaves them)
+    c[na:, kb:] = 0
+    c[n - 1, kb - 1] = 10_000 // (rank + 1)  # the last node's MAP block is the very last block
+    return c
+
+
+def _wide_worker(rank, world, port, out_dir, n, na, ka, kb):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shard = D.ChainShard(4)
+        lab = shard.map_labels(torch.from_numpy(_wide_counts(rank, n, na, ka, kb)), na, ka)
+        assert lab.dtype == (torch.int32 if ka + max(ka, kb) > 256 else torch.uint8)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "wide_map.npy"), lab.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,na,ka,kb", [(33, 16, 300, 310), (32, 16, 300, 310), (33, 16, 100, 120), (3, 1, 2, 2)])
+def test_world2_map_labels_above_256_blocks_and_uneven_rows(tmp_path, n, na, ka, kb):
+    """Labels of a wide handle (two-byte labels inside the library) do not fit a byte: the pooled MAP labels come back as
+    int32, and a node count that does not divide by the world size (the tail rows) is handled without a padded copy."""
+    mp.spawn(_wide_worker, args=(2, _free_port(), str(tmp_path), n, na, ka, kb), nprocs=2, join=True)
+    got = np.load(tmp_path / "wide_map.npy")
+    pooled = _wide_counts(0, n, na, ka, kb).astype(np.int64) + _wide_counts(1, n, na, ka, kb)
+    want = pooled.argmax(axis=1) + np.where(np.arange(n) >= na, ka, 0)
+    assert got.shape == (n,) and (got == want).all()
+    assert got[-1] == ka + kb - 1
+
+
 def test_single_process_paths():
     shard = D.ChainShard(5, rank=0, world_size=1)
     x = torch.arange(10, dtype=torch.float64).reshape(5, 2)
@@ -150,7 +186,11 @@ def _marg_worker(rank, world, port, out_dir):
     try:
         shard = D.ChainShard(TOTAL_CHAINS)
         model = _OracleChains(shard.first_chain_id, shard.n_local)
-        labels, counts = B.marginalize(model, 2, 3, 1, shard=shard)
+        labels, counts = B.marginalize(model, 2, 3, 1, shard=shard, return_counts=True)
+        # over several ranks the pooled histogram is not returned unless asked for (it costs an all_reduce of n x kmax)
+        model2 = _OracleChains(shard.first_chain_id, shard.n_local)
+        labels2, none = B.marginalize(model2, 2, 3, 1, shard=shard)
+        assert none is None and (labels2 == labels).all()
         if rank == 0:
             np.save(os.path.join(out_dir, "m_labels.npy"), labels)
             np.save(os.path.join(out_dir, "m_counts.npy"), counts)

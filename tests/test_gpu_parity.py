@@ -285,7 +285,13 @@ def test_pass_depth_is_chosen_from_timed_launches_and_never_changes_results(monk
         rates = [mh.anneal(g, "constant", [1.0], 1234 * n + 77, BIG).copy(),  # (not a whole number of sweeps)
                  mh.anneal(g, "constant", [0.5], 300 * n, BIG).copy(),        # T < 1, the early stop out of reach
                  mh.anneal(g, "constant", [0.5], 300 * n, 150 * n).copy(),    # ... in reach: one launch
-                 mh.anneal(g, "exponential", [2.0, 0.99999], 200 * n, BIG).copy()]
+                 mh.anneal(g, "exponential", [2.0, 0.99999], 200 * n, BIG).copy(),
+                 # steps_await = 0 at T >= 1: `u = 0 >= 0` after the FIRST sweep (metropolis_hasting.cc:96-98): one sweep, rate
+                 # accepted / N, however long the call -- and steps_await = 5 (< N): u stays 0 at T = 1, the call runs to its end
+                 mh.anneal(g, "constant", [1.0], 500 * n, 0).copy()]
+        assert (g.last_counts()[1] == 1).all() and (g.last_counts()[0] == np.round(rates[4] * n)).all()
+        rates.append(mh.anneal(g, "constant", [1.0], 450 * n, 5).copy())
+        assert (g.last_counts()[1] == 450).all()
         log = capfd.readouterr().err
         out[pin] = (rates, [g.get_memberships(c) for c in range(7)], g.get_entropy(), g.last_counts())
         if pin is None:
@@ -307,6 +313,9 @@ def test_pass_depth_is_chosen_from_timed_launches_and_never_changes_results(monk
     assert o.anneal("constant", [0.5], 300 * n, BIG) == ref[0][1][3]
     assert o.anneal("constant", [0.5], 300 * n, 150 * n) == ref[0][2][3]
     assert o.anneal("exponential", [2.0, 0.99999], 200 * n, BIG) == ref[0][3][3]
+    assert o.anneal("constant", [1.0], 500 * n, 0) == ref[0][4][3]
+    assert o.last_sweeps == 1
+    assert o.anneal("constant", [1.0], 450 * n, 5) == ref[0][5][3]
     assert (o.memberships() == ref[1][3]).all()
     assert (o.last_accepted, o.last_sweeps) == (int(ref[3][0][3]), int(ref[3][1][3]))
 
