@@ -47,6 +47,10 @@ _f32p = C.POINTER(C.c_float)
 ABI = {
     "bisbm_abi_version": (C.c_int, []),
     "bisbm_check_shape": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int]),
+    "bisbm_create_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint64, C.c_uint64, C.c_uint64, _u64p, _u32p, C.c_uint32, C.c_uint32,
+                                     C.c_double, C.c_uint32, C.c_uint32, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_uint64, C.c_uint64]),
+    "bisbm_device_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _u32p]),
+    "bisbm_marginals_map": (C.c_int, [C.c_void_p, _u32p]),
     "bisbm_last_error": (C.c_char_p, [C.c_void_p]),
     "bisbm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint64, C.c_uint64, C.c_uint64, _u64p, _u32p,
                                C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
@@ -282,7 +286,9 @@ class BlockModel:
     """
 
     def __init__(self, memberships, types, g, KA, KB, epsilon, adj, *, n_chains=1, rng="philox", seed=0,
-                 gen_seed=0, device=0, first_chain_id=0):
+                 gen_seed=0, device=0, first_chain_id=0, devices=None):
+        """``devices``: a list of HIP device ordinals -- the chains are spread over them as contiguous ranges behind ONE handle
+        (``bisbm_create_multi``); every result equals what a single device with all the chains gives."""
         L = lib()
         self._L = L
         types = np.asarray(types)
@@ -312,9 +318,17 @@ class BlockModel:
             except Exception:
                 pass
         h = C.c_void_p()
-        rc = L.bisbm_create(C.byref(h), self.n, self.na, self.nb, _p(rowptr, _u64p), _p(col, _u32p), self.KA,
-                            self.KB, self.epsilon, self.n_chains, int(first_chain_id), int(device),
-                            _RNG[rng] if isinstance(rng, str) else int(rng), int(seed), int(gen_seed))
+        self.devices = [int(d) for d in devices] if devices is not None else [int(device)]
+        if devices is not None:
+            self.device = self.devices[0]
+            devs = (C.c_int * len(self.devices))(*self.devices)
+            rc = L.bisbm_create_multi(C.byref(h), self.n, self.na, self.nb, _p(rowptr, _u64p), _p(col, _u32p), self.KA,
+                                      self.KB, self.epsilon, self.n_chains, int(first_chain_id), devs, len(self.devices),
+                                      _RNG[rng] if isinstance(rng, str) else int(rng), int(seed), int(gen_seed))
+        else:
+            rc = L.bisbm_create(C.byref(h), self.n, self.na, self.nb, _p(rowptr, _u64p), _p(col, _u32p), self.KA,
+                                self.KB, self.epsilon, self.n_chains, int(first_chain_id), int(device),
+                                _RNG[rng] if isinstance(rng, str) else int(rng), int(seed), int(gen_seed))
         if rc != BISBM_OK:
             raise BisbmError(rc, (L.bisbm_last_error(None) or b"").decode())
         self._h = h
@@ -416,8 +430,11 @@ class BlockModel:
     def _refresh_k(self):
         """KA / KB / K of the model: the counts all chains share, or -- once a one-argument agg_merge has left the chains
         with different ones (``mixed_shapes``) -- those of chain 0; ``ka_kb(chain)`` is always per chain."""
-        shapes = {self.ka_kb(c) for c in range(self.n_chains)} if self.n_chains <= 4096 else {self.ka_kb(0)}
-        self.mixed_shapes = len(shapes) > 1
+        ka, kb = C.c_uint32(), C.c_uint32()
+        rc = self._L.bisbm_get_ka_kb(self._h, C.byref(ka), C.byref(kb))  # one call whatever the chain count:
+        self.mixed_shapes = rc == BISBM_ERR_STATE                          # BISBM_ERR_STATE = the chains differ in shape
+        if rc not in (BISBM_OK, BISBM_ERR_STATE):
+            self._check(rc)
         self.KA, self.KB = self.ka_kb(0)
         self.K = self.KA + self.KB
 
@@ -477,6 +494,21 @@ class BlockModel:
         out = np.zeros((self.n, self.kmax), dtype=np.uint32)
         self._check(self._L.bisbm_marginals_get(self._h, _p(out, _u32p)))
         return out
+
+    def marginals_map(self):
+        """MAP block of every node from the internal histogram (most frequent block, ties -> the lowest), pooled over the
+        handle's devices on the devices (``bisbm_marginals_map``: reduce-scatter -> argmax -> all-gather)."""
+        out = np.zeros(self.n, dtype=np.uint32)
+        self._check(self._L.bisbm_marginals_map(self._h, _p(out, _u32p)))
+        return out
+
+    def device_layout(self):
+        """(device ordinals, first chain of each device) behind this handle."""
+        nd = C.c_int()
+        self._check(self._L.bisbm_device_count(self._h, C.byref(nd), None, None))
+        devs, first = (C.c_int * nd.value)(), np.zeros(nd.value, dtype=np.uint32)
+        self._check(self._L.bisbm_device_count(self._h, C.byref(nd), devs, _p(first, _u32p)))
+        return list(devs), first.tolist()
 
     def debug_log_q(self, n, k, fast=False):
         n = np.ascontiguousarray(n, dtype=np.int32)

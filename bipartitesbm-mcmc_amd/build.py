@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbisbm_hip.so")
 SOURCES = ["bisbm_kernels.hip", "bisbm_sweep_fast.hip", "bisbm_runtime.hip", "bisbm_io.cpp"]
-HEADERS = ["bisbm_device.hpp", "bisbm_kernels.hpp", os.path.join("..", "host", "bisbm.hpp"),
+HEADERS = ["bisbm_device.hpp", "bisbm_kernels.hpp", "bisbm_multi.hpp", os.path.join("..", "host", "bisbm.hpp"),
            os.path.join("..", "host", "mcmc_main.cpp"), os.path.join("..", "..", "include", "bisbm.h"),
            os.path.join("..", "..", "include", "bisbm_io.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",

@@ -56,14 +56,48 @@ __device__ __forceinline__ double dpp_f64(double x) {
     return __hiloint2double(hi, lo);
 }
 
-// Fixed 64-leaf xor butterfly, levels 1,2,4,8,16,32: the summation tree of Philox mode (the CPU checker
-// restates the same tree).  Levels 1 and 2 are quad permutes; after them every lane of a quad holds
-// the quad's sum, so the mirror permutes pair the same partial sums as xor 4 / xor 8 would (FP add
-// is commutative: same bits); levels 16 and 32 add the four row sums as (R0+R1)+(R2+R3): R1 += R0 and
-// R3 += R2 (row_bcast15 into rows 1,3), then R3 += R1 (row_bcast31 into rows 2,3).  Only row 3 is
-// complete at the end (rows 0 and 2 pick up garbage from the masked moves); lane 63 is returned
-// wave-uniform.
+// Fixed 64-leaf xor butterfly, levels 32, then 1,2,4,8,16: the summation tree of Philox mode (the CPU checker restates the
+// same tree).  Level 32 comes first -- leaf l + leaf l ^ 32, one v_permlane32_swap pair: afterwards both halves of the wave hold
+// the same 32 partial sums, which is what lets a variant that keeps TWO leaves per lane (two steps per pass with more than 32
+// blocks) add its own pair first, and two sums share one butterfly (butterfly_pair64).  Levels 1 and 2 are quad permutes; after
+// them every lane of a quad holds the quad's sum, so the mirror permutes pair the same partial sums as xor 4 / xor 8 would (FP
+// add is commutative: same bits); level 16 is R1 += R0 (row_bcast15 into rows 1, 3).  With at most 32 / 16 / 8 leaves in use
+// the others are +0.0 and the levels that only add them drop out (butterfly_sum_low32, butterfly_rows16, butterfly_groups8:
+// same bits).  Rows 1 and 3 are complete at the end; lane 63 is returned wave-uniform.
+__device__ __forceinline__ double butterfly_fold32(double x) {  // every lane: leaf l + leaf l ^ 32
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(x), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(x), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);  // [x.lo, x.lo] + [x.hi, x.hi]
+}
 __device__ __forceinline__ double butterfly_sum(double x) {
+    x = butterfly_fold32(x);
+    x = x + dpp_f64<kDppXor1>(x);
+    x = x + dpp_f64<kDppXor2>(x);
+    x = x + dpp_f64<kDppHalfMirror>(x);
+    x = x + dpp_f64<kDppMirror>(x);
+    x = x + dpp_f64<kDppBcast15, 0xA>(x);
+    return readlane(x, 63u);
+}
+
+// Two 64-leaf butterfly sums for the price of one: the swap that folds a (lanes 0..31 + lanes 32..63) leaves the lower half for
+// a's fold and the upper half for b's, and the five row levels run once for both.  Same tree, same bits as butterfly_sum(a),
+// butterfly_sum(b).
+__device__ __forceinline__ void butterfly_pair64(double a, double b, double& sum_a, double& sum_b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    double x = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);  // [a.lo, b.lo] + [a.hi, b.hi]
+    x = x + dpp_f64<kDppXor1>(x);
+    x = x + dpp_f64<kDppXor2>(x);
+    x = x + dpp_f64<kDppHalfMirror>(x);
+    x = x + dpp_f64<kDppMirror>(x);
+    x = x + dpp_f64<kDppBcast15, 0xA>(x);
+    sum_a = readlane(x, 31u);
+    sum_b = readlane(x, 63u);
+}
+
+// The tree of rounds 1 and 2 (levels 1,2,4,8,16,32 in that order), kept for entropy()'s block-state sum, whose recorded
+// reference values are compared to 1e-13.
+__device__ __forceinline__ double butterfly_sum_levels_up(double x) {
     x = x + dpp_f64<kDppXor1>(x);
     x = x + dpp_f64<kDppXor2>(x);
     x = x + dpp_f64<kDppHalfMirror>(x);
@@ -75,7 +109,7 @@ __device__ __forceinline__ double butterfly_sum(double x) {
 
 // Two butterfly sums at once when both inputs are zero in lanes 32..63 (at most 32 leaves in use): b is
 // moved to the upper half with v_permlane32_swap and one 32-leaf butterfly per half gives both sums
-// (rows 1 and 3 are the complete ones).  Same tree as butterfly_sum: its last level would only add the
+// (rows 1 and 3 are the complete ones).  Same tree as butterfly_sum: its first level would only add the
 // empty upper half (x + 0.0 = x).
 __device__ __forceinline__ void butterfly_pair32(double a, double b, double& sum_a, double& sum_b) {
     const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
@@ -90,7 +124,7 @@ __device__ __forceinline__ void butterfly_pair32(double a, double b, double& sum
     sum_b = readlane(x, 63u);
 }
 
-// The sum of a 64-leaf butterfly whose leaves 32..63 are all +0.0: its level 32 adds x + 0.0 = x, so the
+// The sum of a 64-leaf butterfly whose leaves 32..63 are all +0.0: its level 32 (the first) adds x + 0.0 = x, so the
 // five levels of the lower half give the same bits.
 __device__ __forceinline__ double butterfly_sum_low32(double x) {
     x = x + dpp_f64<kDppXor1>(x);

@@ -874,7 +874,7 @@ __global__ __launch_bounds__(kWave) void entropy_kernel(EntropyParams p) {
         ent += lgamma_fast(tab, (long long)mr_g[r] + 1);
         ent += log_q<false>(tab, mr_g[r], nr_g[r]);
     }
-    ent = butterfly_sum(ent);
+    ent = butterfly_sum_levels_up(ent);
     if (lane == 0) p.out[chain] = ent;
 }
 
@@ -905,6 +905,32 @@ __global__ __launch_bounds__(256) void marginals_kernel(MarginalParams p) {
         uint32_t* out = p.counts + (size_t)v * p.kmax;
         for (uint32_t c = 0; c < p.n_chains; ++c) out[(uint32_t)labels[(size_t)c * p.label_stride + v] - base] += 1;
     }
+}
+
+// MAP block of the nodes first .. first + rows - 1 from (a slice of) the pooled histogram: the most frequent block of the
+// node's type, ties -> the lowest index (README.md:49-53: "the marginal estimate"), in the reference's numbering (type-b
+// blocks offset by ka).  Thread = node; `counts` points at the row of node `first`.
+__global__ __launch_bounds__(256) void marginal_map_kernel(const uint32_t* counts, uint32_t rows, uint32_t kmax, uint32_t first,
+                                                           uint32_t n, uint32_t na, uint32_t ka, uint16_t* labels_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const uint32_t v = first + i;
+    uint32_t best = 0, arg = 0;
+    if (v < n) {
+        const uint32_t* row = counts + (size_t)i * kmax;
+        for (uint32_t j = 0; j < kmax; ++j) {
+            const uint32_t c = row[j];
+            if (c > best) best = c, arg = j;
+        }
+        arg += v < na ? 0u : ka;
+    }
+    labels_out[i] = (uint16_t)arg;
+}
+
+// a[i] += b[i]: the owner of a node range adds another device's slice of the histogram (peer-copy pooling path)
+__global__ __launch_bounds__(256) void counts_add_kernel(uint32_t* a, const uint32_t* b, size_t count) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < count) a[i] += b[i];
 }
 
 __global__ void log_q_probe_kernel(Tables tab, const int32_t* n, const int32_t* k, size_t count, double* out,
@@ -1290,6 +1316,19 @@ hipError_t launch_log_q_probe(const Tables& tab, const int32_t* n, const int32_t
                               int fast, hipStream_t stream) {
     hipLaunchKernelGGL(log_q_probe_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, tab, n, k,
                        count, out, fast);
+    return hipGetLastError();
+}
+
+hipError_t launch_marginal_map(const uint32_t* counts, uint32_t rows, uint32_t kmax, uint32_t first, uint32_t n, uint32_t na,
+                               uint32_t ka, uint16_t* labels_out, hipStream_t stream) {
+    if (rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(marginal_map_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, counts, rows, kmax, first, n, na, ka, labels_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_counts_add(uint32_t* a, const uint32_t* b, size_t count, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(counts_add_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, a, b, count);
     return hipGetLastError();
 }
 

@@ -26,6 +26,14 @@ struct ChainScalars {
     uint32_t hw_id[2];
     uint32_t xcc_id;
     uint32_t split_epoch;  // Philox counter: agg_split calls so far
+    // anneal()'s early-stop bookkeeping (metropolis_hasting.cc:75,85-98) where one call runs as several launches of the
+    // production kernel: the minimum of sum dS so far, the count of T < 1 steps before the step that reached it, the
+    // count of T < 1 steps so far, and whether the chain has returned already (SweepParams::resume)
+    double stop_emin;
+    uint64_t stop_mark;
+    uint64_t stop_below1;
+    uint32_t stopped;
+    uint32_t pad_;
 };
 
 struct SweepParams {
@@ -53,15 +61,24 @@ struct SweepParams {
     const double* q_tab;
     uint32_t q_stride;
     const double* log_tab;
-    const double* T_tab;  // host-evaluated temperatures for the pow/log schedules
+    const double* T_tab;  // host-evaluated temperatures for the pow/log schedules: entry i is step T_base + i of the call
     uint64_t T_len;
+    uint64_t T_base;
     int T_zero_after;
     // schedule / run
     int schedule;
     float kw0, kw1;
     uint64_t duration, steps_await;
+    // production kernel, a call that runs as several launches: steps of the call executed by the launches before (whole
+    // sweeps), the call's full duration, and resume = 1 from the second launch on (the early-stop bookkeeping continues from
+    // the chain's scalars; chains that have returned are skipped).  One launch per call: 0, duration, 0.
+    uint64_t t_base, call_duration;
+    uint32_t resume;
     uint64_t seed;
     int eta_in_lds;
+    // production kernel without all of eta in LDS: the window it keeps there instead -- eta_w consecutive degrees per block of
+    // the phase's own type, from eta_lo_a (type-a phase) / eta_lo_b on; nodes of other degrees take the general step
+    uint32_t eta_w, eta_lo_a, eta_lo_b;
     int vlist_in_lds;
     // production kernel: one counter per SIMD of the chip (kSimdClaims entries, zeroed before the launch) through which
     // the workgroups keep their stepping waves on different SIMDs; NULL: wave `fixed_stepping_wave` (0 or 1) steps
@@ -181,9 +198,27 @@ __device__ __forceinline__ double temperature_of(const SweepParams& p, uint64_t 
     }
 }
 
+// The production kernel's temperatures: the pow / log schedules come from the host table only (glibc, the reference's own
+// values) -- bisbm_anneal hands every launch the slice of the call it covers, so no pow() / log() is compiled into that
+// kernel (they cost it 30 - 110 spilled vector registers in the cooling-schedule variants).
+__device__ __forceinline__ double temperature_tabled(const SweepParams& p, uint64_t t) {
+    switch (p.schedule) {
+        case SCHED_CONSTANT:
+            return (double)p.kw0;
+        case SCHED_ABRUPT:
+            return ((float)t < p.kw0) ? 1. : 0.;
+        case SCHED_LINEAR:
+            return (double)(p.kw0 - p.kw1 * (float)t);
+        default: {  // SCHED_EXPONENTIAL, SCHED_LOGARITHMIC
+            const uint64_t i = t - p.T_base;
+            return i < p.T_len ? p.T_tab[i] : 0.;  // (past the table: the exponential schedule after it has underflowed to 0)
+        }
+    }
+}
+
 hipError_t launch_sweep(const SweepParams& p, int rng_mode, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_sweep_fast(const SweepParams& p, size_t lds_bytes, hipStream_t stream);
-size_t sweep_fast_lds_bytes(uint32_t ka, uint32_t kb, uint32_t maxdeg, bool eta_in_lds);
+size_t sweep_fast_lds_bytes(uint32_t ka, uint32_t kb, uint32_t maxdeg, bool eta_in_lds, uint32_t eta_window);
 hipError_t launch_state_build(const BuildParams& p, hipStream_t stream);
 // `labels` is the byte base of the label array; wide: two-byte labels (label_stride counts labels in both cases)
 hipError_t launch_labels_broadcast(const uint32_t* src, uint8_t* labels, bool wide, size_t label_stride, uint32_t n,
@@ -200,6 +235,10 @@ hipError_t launch_merge_relabel(uint8_t* labels, bool wide, size_t label_stride,
 hipError_t launch_shuffle(const ShuffleParams& p, int rng_mode, hipStream_t stream);
 hipError_t launch_entropy(const EntropyParams& p, hipStream_t stream);
 hipError_t launch_marginals(const MarginalParams& p, hipStream_t stream);
+// MAP labels of `rows` nodes from the histogram rows at `counts` (node `first` on); a += b over `count` counters
+hipError_t launch_marginal_map(const uint32_t* counts, uint32_t rows, uint32_t kmax, uint32_t first, uint32_t n, uint32_t na,
+                               uint32_t ka, uint16_t* labels_out, hipStream_t stream);
+hipError_t launch_counts_add(uint32_t* a, const uint32_t* b, size_t count, hipStream_t stream);
 hipError_t launch_log_q_probe(const Tables& tab, const int32_t* n, const int32_t* k, size_t count, double* out,
                               int fast, hipStream_t stream);
 

@@ -6,11 +6,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -143,26 +145,39 @@ double h_lbinom_fast(const HostTables& t, uint64_t N, uint64_t k) {  // util.hh:
     return (h_lgamma_fast(t, N + 1) - h_lgamma_fast(t, k + 1)) - h_lgamma_fast(t, N - k + 1);
 }
 
-// metropolis_hasting.cc:10-13,20-23 evaluated with the host libm for the first `len` steps
-std::vector<double> schedule_table(int schedule, float kw0, float kw1, uint64_t len, int* zero_after) {
-    std::vector<double> T;
+// metropolis_hasting.cc:10-13,20-23 evaluated with the host libm (the reference's own values) for steps t0 .. t0 + len - 1 of a
+// call, on up to 16 threads.  The exponential schedule's table ends with its first exact zero (pow has underflowed: it is
+// monotone for 0 <= kw1 < 1, so every later step is 0 as well; *zero_after says so).
+std::vector<double> schedule_table(int schedule, float kw0, float kw1, uint64_t t0, uint64_t len, int* zero_after) {
+    std::vector<double> T((size_t)len);
     *zero_after = 0;
-    T.reserve((size_t)std::min<uint64_t>(len, 1u << 16));
-    for (uint64_t t = 0; t < len; ++t) {
-        double v;
-        if (schedule == SCHED_EXPONENTIAL) {
-            v = (double)kw0 * std::pow((double)kw1, (double)t);
-        } else {
-            const float x = (float)t + kw1;
-            const size_t i = (size_t)x;
-            v = (double)kw0 / (i == 0 ? 0. : std::log((double)i));
+    auto fill = [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t j = lo; j < hi; ++j) {
+            const uint64_t t = t0 + j;
+            if (schedule == SCHED_EXPONENTIAL) {
+                T[j] = (double)kw0 * std::pow((double)kw1, (double)t);
+            } else {
+                const float x = (float)t + kw1;
+                const size_t i = (size_t)x;
+                T[j] = (double)kw0 / (i == 0 ? 0. : std::log((double)i));
+            }
         }
-        T.push_back(v);
-        if (schedule == SCHED_EXPONENTIAL && v == 0. && kw1 < 1.f && kw1 >= 0.f) {
-            *zero_after = 1;  // pow is monotone here: every later step is 0 as well
-            break;
-        }
+    };
+    const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), len >> 14));
+    if (nt <= 1) {
+        fill(0, len);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned i = 0; i < nt; ++i) th.emplace_back(fill, len * i / nt, len * (i + 1) / nt);
+        for (auto& x : th) x.join();
     }
+    if (schedule == SCHED_EXPONENTIAL && kw1 < 1.f && kw1 >= 0.f)
+        for (uint64_t j = 0; j < len; ++j)
+            if (T[j] == 0.) {
+                T.resize((size_t)j + 1);
+                *zero_after = 1;
+                break;
+            }
     return T;
 }
 
@@ -216,6 +231,9 @@ struct bisbm_engine {
     uint32_t q_stride = 0;
     // chain-independent part of entropy()
     double ent_deg = 0, ent_multi = 0;
+    // nodes of every degree 0..256 per type (256: all longer rows), shared with the sub-engines: what the production kernel's
+    // eta window is placed by (bisbm_anneal)
+    std::shared_ptr<std::vector<uint64_t>> deg_count;
     // last sweep timing
     double last_kernel_ms = 0;
     uint64_t last_updates = 0;
@@ -235,6 +253,14 @@ struct bisbm_engine {
     std::vector<uint32_t> gids, ridx;
     uint32_t* d_gids = nullptr;
     uint32_t gid(size_t c) const { return gids.empty() ? first_chain_id + (uint32_t)c : gids[c]; }
+    // Several devices behind one handle (bisbm_create_multi): the handle is a container of one full engine per device
+    // (`devs`; graph and tables replicated, one stream and one host thread per device); chains dev_first[i] ..
+    // dev_first[i + 1] - 1 of the handle live in devs[i], in order, so global chain ids -- the keys of the random streams --
+    // do not depend on the number of devices.  `pool`: what the pooling of the marginal histogram over the devices needs.
+    std::vector<bisbm_engine*> devs;
+    std::vector<uint32_t> dev_first;
+    struct DevicePool* pool = nullptr;
+    uint64_t counts_rows = 0;  // rows of the internal marginal buffer (n, or n rounded up to a multiple of the device count)
 };
 
 namespace {
@@ -365,7 +391,36 @@ size_t generic_lds_base_bytes(uint32_t ka, uint32_t kb, bool wide, int rng_mode)
 }
 constexpr size_t kLdsPerCu = 160 * 1024;
 
+// fn(c) for every chain, on up to 16 host threads when there are enough chains.  An exception that left a worker thread
+// (std::bad_alloc from a chain's host-side merge state) would end the process through std::terminate, and one that left
+// the calling thread would cross the C boundary: both are caught here and reported as `false`.
+template <class F>
+bool for_each_chain(size_t C, F&& fn) {
+    std::atomic<bool> ok{true};
+    auto guarded = [&](size_t c) {
+        try {
+            fn(c);
+        } catch (...) {
+            ok = false;
+        }
+    };
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, std::thread::hardware_concurrency()), C / 4));
+    if (nt <= 1) {
+        for (size_t c = 0; c < C; ++c) guarded(c);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back([&, t] {
+                for (size_t c = t; c < C; c += nt) guarded(c);
+            });
+        for (auto& x : th) x.join();
+    }
+    return ok;
+}
+
 }  // namespace
+
+#include "bisbm_multi.hpp"
 
 extern "C" {
 
@@ -410,10 +465,12 @@ int bisbm_create(bisbm_handle* out, uint64_t n, uint64_t na, uint64_t nb, const 
     const uint64_t nnz = rowptr[n];
     if (nnz % 2) return fail(nullptr, BISBM_ERR_INVALID_ARG, "odd number of adjacency entries");
     uint32_t maxdeg = 0;
+    auto deg_count = std::make_shared<std::vector<uint64_t>>(2 * 257, 0);
     for (uint64_t v = 0; v < n; ++v) {
         if (rowptr[v + 1] < rowptr[v]) return fail(nullptr, BISBM_ERR_INVALID_ARG, "rowptr is not monotone");
         maxdeg = std::max<uint32_t>(maxdeg, (uint32_t)(rowptr[v + 1] - rowptr[v]));
         const bool vb = v >= na;
+        ++(*deg_count)[(vb ? 257 : 0) + std::min<uint64_t>(rowptr[v + 1] - rowptr[v], 256)];
         for (uint64_t e = rowptr[v]; e < rowptr[v + 1]; ++e) {
             if (col[e] >= n) return fail(nullptr, BISBM_ERR_NOT_BIPARTITE, "neighbour id %u >= n", col[e]);
             if ((col[e] >= na) == vb)
@@ -438,6 +495,7 @@ int bisbm_create(bisbm_handle* out, uint64_t n, uint64_t na, uint64_t nb, const 
     h->kb = kb;
     h->K = ka + kb;
     h->maxdeg = maxdeg;
+    h->deg_count = deg_count;
     h->n_chains = n_chains;
     h->first_chain_id = first_chain_id;
     h->epsilon = epsilon;
@@ -558,6 +616,7 @@ int bisbm_create(bisbm_handle* out, uint64_t n, uint64_t na, uint64_t nb, const 
 
 int bisbm_destroy(bisbm_handle h) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!h->devs.empty()) multi_free(h);
     free_all(h);
     delete h;
     return BISBM_OK;
@@ -565,6 +624,7 @@ int bisbm_destroy(bisbm_handle h) {
 
 int bisbm_set_stream(bisbm_handle h, void* hip_stream) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!h->devs.empty()) return fail(h, BISBM_ERR_UNSUPPORTED, "a handle over several devices runs every device on a stream of its own");
     for (bisbm_engine* g : h->groups) g->stream = hip_stream ? (hipStream_t)hip_stream : g->own_stream;
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return BISBM_OK;
@@ -575,6 +635,14 @@ int bisbm_set_memberships(bisbm_handle h, int64_t chain, const uint32_t* labels)
     if (!labels) return fail(h, BISBM_ERR_INVALID_ARG, "labels is NULL");
     if (chain != BISBM_ALL_CHAINS && (chain < 0 || chain >= (int64_t)h->n_chains))
         return fail(h, BISBM_ERR_INVALID_ARG, "chain %lld out of range", (long long)chain);
+    if (!h->devs.empty()) {
+        if (chain == BISBM_ALL_CHAINS) return on_devices(h, [&](bisbm_engine* d, size_t) { return bisbm_set_memberships(d, BISBM_ALL_CHAINS, labels); });
+        uint32_t local;
+        bisbm_engine* d = h->devs[dev_of_chain(h, (uint32_t)chain, &local)];
+        const int rc = bisbm_set_memberships(d, local, labels);
+        if (rc) h->err = d->err;
+        return rc;
+    }
     if (!h->groups.empty()) {  // (the labels must name blocks of the chain's own shape)
         if (chain == BISBM_ALL_CHAINS) return each_group(h, [&](bisbm_engine* g) { return bisbm_set_memberships(g, BISBM_ALL_CHAINS, labels); });
         bisbm_engine* g = h->groups[h->where[chain].first];
@@ -599,6 +667,7 @@ int bisbm_set_memberships(bisbm_handle h, int64_t chain, const uint32_t* labels)
 
 int bisbm_init(bisbm_handle h) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!h->devs.empty()) return on_devices(h, [](bisbm_engine* d, size_t) { return bisbm_init(d); });
     if (!h->groups.empty()) return each_group(h, [](bisbm_engine* g) { return bisbm_init(g); });
     HIPCHK(h, hipSetDevice(h->device));
     return rebuild_state(h);
@@ -606,6 +675,7 @@ int bisbm_init(bisbm_handle h) {
 
 int bisbm_shuffle(bisbm_handle h) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!h->devs.empty()) return on_devices(h, [](bisbm_engine* d, size_t) { return bisbm_shuffle(d); });
     if (!h->groups.empty()) return each_group(h, [](bisbm_engine* g) { return bisbm_shuffle(g); });
     HIPCHK(h, hipSetDevice(h->device));
     ShuffleParams sp{};
@@ -635,6 +705,7 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     if (!kwargs) return fail(h, BISBM_ERR_INVALID_ARG, "kwargs is NULL");
     if (schedule < BISBM_SCHED_EXPONENTIAL || schedule > BISBM_SCHED_ABRUPT_COOL)
         return fail(h, BISBM_ERR_INVALID_ARG, "unknown schedule %d", schedule);
+    if (!h->devs.empty()) return multi_anneal(h, schedule, kwargs, duration_steps, steps_await, acc_rate_out);
     if (!h->groups.empty()) {
         // one launch per shape, all in flight together: every group has a stream of its own, and a host thread per group
         // makes the (blocking) call; kernel time is reported as the longest group's, updates as the sum
@@ -701,17 +772,28 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     p.steps_await = steps_await;
     p.seed = h->seed;
 
-    // temperatures of the pow/log schedules are evaluated with the host libm (the reference's own)
+    p.t_base = 0;
+    p.call_duration = duration_steps;
+    p.resume = 0;
+    // the production kernel covers Philox mode with both block counts <= 64; mt19937-compat mode and
+    // wider partitions run the generic kernel (BISBM_FORCE_GENERIC=1 forces it, for A/B checks)
+    const char* force = getenv("BISBM_FORCE_GENERIC");
+    const bool fast = h->rng_mode == BISBM_RNG_PHILOX && h->ka <= 64 && h->kb <= 64 && !h->wide && !(force && force[0] == '1');
+    // Temperatures of the pow / log schedules are evaluated with the host libm (the reference's own values) into a table of
+    // at most kTabCap steps.  The generic kernel evaluates pow / log itself beyond it; the production kernel holds no
+    // pow / log at all: a longer call runs as several launches of whole sweeps, each with the slice of the table it covers
+    // (the early-stop bookkeeping carries over in the chain's scalars, SweepParams::resume).
+    const bool tabled = schedule == BISBM_SCHED_EXPONENTIAL || schedule == BISBM_SCHED_LOGARITHMIC;
+    const uint64_t kTabCap = getenv("BISBM_T_TABLE_CAP") ? std::max<uint64_t>(1, strtoull(getenv("BISBM_T_TABLE_CAP"), nullptr, 10)) : (1ull << 22);  // (the variable: tests)
     p.T_tab = nullptr;
     p.T_len = 0;
+    p.T_base = 0;
     p.T_zero_after = 0;
-    if (schedule == BISBM_SCHED_EXPONENTIAL || schedule == BISBM_SCHED_LOGARITHMIC) {
-        const uint64_t cap = 1ull << 22;
-        int zero_after = 0;
-        std::vector<double> T = schedule_table(schedule, p.kw0, p.kw1, std::min(duration_steps, cap), &zero_after);
+    auto upload_table = [&](const std::vector<double>& T, uint64_t t0, int zero_after) -> int {
         if (T.size() > h->d_T_cap) {
             if (h->d_T) (void)hipFree(h->d_T);
             h->d_T = nullptr;
+            h->d_T_cap = 0;
             HIPCHK(h, dalloc(&h->d_T, T.size()));
             h->d_T_cap = T.size();
         }
@@ -720,22 +802,50 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
         HIPCHK(h, hipStreamSynchronize(h->stream));
         p.T_tab = h->d_T;
         p.T_len = T.size();
+        p.T_base = t0;
         p.T_zero_after = zero_after;
+        return BISBM_OK;
+    };
+    const uint64_t total_sweeps = duration_steps / h->n;
+    // (a table slice covers whole sweeps: at least one, however large the graph)
+    const uint64_t tab_seg = std::max<uint64_t>(1, kTabCap / h->n);
+    const bool tab_segments = fast && tabled && total_sweeps > tab_seg;
+    if (tabled && !tab_segments) {
+        int zero_after = 0;
+        const std::vector<double> T = schedule_table(schedule, p.kw0, p.kw1, 0, fast ? total_sweeps * h->n : std::min(duration_steps, kTabCap), &zero_after);
+        if (int rc = upload_table(T, 0, zero_after)) return rc;
     }
-
-    // the production kernel covers Philox mode with both block counts <= 64; mt19937-compat mode and
-    // wider partitions run the generic kernel (BISBM_FORCE_GENERIC=1 forces it, for A/B checks)
-    const char* force = getenv("BISBM_FORCE_GENERIC");
-    const bool fast = h->rng_mode == BISBM_RNG_PHILOX && h->ka <= 64 && h->kb <= 64 && !h->wide && !(force && force[0] == '1');
     // LDS plan.  eta goes to LDS when that still leaves room for four chains per CU (160 KiB / 4).
-    const size_t K = h->K, D = (size_t)h->maxdeg + 1, S = h->kb | 1u;
+    const size_t K = h->K, D = (size_t)h->maxdeg + 1;
     const size_t eta_bytes = sizeof(uint32_t) * K * D;
     size_t lds;
     p.vlist_in_lds = 0;
+    p.eta_w = p.eta_lo_a = p.eta_lo_b = 0;
     if (fast) {
-        lds = sweep_fast_lds_bytes(h->ka, h->kb, h->maxdeg, false);
+        lds = sweep_fast_lds_bytes(h->ka, h->kb, h->maxdeg, false, 0);
         p.eta_in_lds = (lds + eta_bytes <= 40 * 1024) ? 1 : 0;
-        lds = sweep_fast_lds_bytes(h->ka, h->kb, h->maxdeg, p.eta_in_lds != 0);
+        if (!p.eta_in_lds) {
+            // eta does not fit beside the rest (many blocks and / or long rows): the kernel keeps a window of it in LDS -- the
+            // rows of the phase's own type, `eta_w` consecutive degrees -- placed per type where most nodes are (only rows of 1 to
+            // 255 neighbours take the hot step at all); nodes of other degrees take the general step with eta in HBM
+            const uint32_t kmax = std::max(h->ka, h->kb);
+            const size_t room = lds < 40 * 1024 ? (40 * 1024 - lds) / (sizeof(uint32_t) * kmax) : 0;
+            p.eta_w = (uint32_t)std::max<size_t>(1, std::min<size_t>(room, D));
+            if (const char* w = getenv("BISBM_ETA_WINDOW")) p.eta_w = (uint32_t)std::max(1l, std::min<long>(atol(w), (long)D));  // (tests)
+            for (int type = 0; type < 2; ++type) {
+                const uint64_t* cnt = h->deg_count->data() + 257 * type;
+                uint64_t in = 0, best = 0;
+                uint32_t best_lo = 1;
+                for (uint32_t d = 1; d <= 255; ++d) {  // window [d - eta_w + 1, d]
+                    in += cnt[d];
+                    if (d > p.eta_w) in -= cnt[d - p.eta_w];
+                    const uint32_t lo = d >= p.eta_w ? d - p.eta_w + 1 : 1;
+                    if (in > best) best = in, best_lo = lo;
+                }
+                (type ? p.eta_lo_b : p.eta_lo_a) = best_lo;
+            }
+        }
+        lds = sweep_fast_lds_bytes(h->ka, h->kb, h->maxdeg, p.eta_in_lds != 0, p.eta_w);
     } else {
         // generic kernel: m quadrant (odd row stride), m_r, n_r, k_v histogram, staged rows; compat adds the
         // two mt19937 states and (small graphs) the visit list
@@ -776,34 +886,64 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     // where the chain is, so it is MEASURED: every launch is timed, the depth with the best updates per ms so far runs, and
     // every sixteenth launch tries a neighbouring depth again (a chain leaves its burn-in).  The chain is the same chain whatever
     // runs (same Philox counters, bit-equal results).
-    const uint64_t total_sweeps = duration_steps / h->n;
     const uint32_t max_depth = (!fast || p.pair_steps < 2u || h->ka > 16 || h->kb > 16) ? 0u
                                : std::min<uint32_t>(p.pair_steps, (h->ka <= 8 && h->kb <= 8) ? 3u : 2u);
     // ("no early stop in reach": at T >= 1 the count u of metropolis_hasting.cc:85-98 stays 0, so the test `u >= steps_await`
     // after a sweep fires exactly when steps_await == 0 -- then the call ends after its FIRST sweep with rate accepted / N
     // (:96-98) and must stay one launch; below T = 1 the count gains at most one per step)
-    const bool segmented = max_depth >= 2u && schedule == SCHED_CONSTANT &&
-                           ((kwargs[0] >= 1.f && steps_await > 0) || steps_await > duration_steps) && kwargs[0] > 0.f && total_sweeps >= 2;
+    const bool depth_segments = max_depth >= 2u && schedule == SCHED_CONSTANT &&
+                                ((kwargs[0] >= 1.f && steps_await > 0) || steps_await > duration_steps) && kwargs[0] > 0.f && total_sweeps >= 2;
+    const bool segmented = depth_segments || tab_segments;
     std::vector<ChainScalars> sc(h->n_chains);
     std::vector<uint64_t> acc_sum(h->n_chains, 0), sweeps_sum(h->n_chains, 0);
     double ms_sum = 0;
-    uint64_t updates = 0, sweeps_left = segmented ? total_sweeps : 0;
-    const uint64_t seg = std::max<uint64_t>(1, (100000 + h->n - 1) / h->n);  // >= 10^5 steps per chain and launch: tens of ms
+    uint64_t updates = 0, sweeps_left = segmented ? total_sweeps : 0, sweeps_done = 0;
+    const uint64_t seg = tab_segments ? tab_seg : std::max<uint64_t>(1, (100000 + h->n - 1) / h->n);  // depth: >= 10^5 steps per chain and launch: tens of ms
+    // the table slice of the next launch is evaluated on the host while the current launch runs
+    struct Slice {
+        std::vector<double> T;
+        int zero_after = 0;
+    };
+    auto slice_sweeps = [&](uint64_t left) { return (tab_segments || left >= 2 * seg) ? std::min(left, seg) : left; };
+    std::future<Slice> next_slice;
+    auto start_slice = [&](uint64_t first_sweep, uint64_t count) {
+        const int sched = schedule;
+        const float k0 = p.kw0, k1 = p.kw1;
+        const uint64_t t0 = first_sweep * h->n, len = count * h->n;
+        next_slice = std::async(std::launch::async, [sched, k0, k1, t0, len] {
+            Slice sl;
+            sl.T = schedule_table(sched, k0, k1, t0, len, &sl.zero_after);
+            return sl;
+        });
+    };
+    if (tab_segments) start_slice(0, slice_sweeps(sweeps_left));
     bool first = true;
     while (first || sweeps_left > 0) {
-        first = false;
         if (segmented) {
-            const uint64_t now = sweeps_left < 2 * seg ? sweeps_left : seg;
+            const uint64_t now = slice_sweeps(sweeps_left);
             p.duration = now * h->n;
+            p.t_base = sweeps_done * h->n;
+            p.resume = first ? 0u : 1u;
+            if (tab_segments) {
+                Slice sl;
+                try {
+                    sl = next_slice.get();
+                } catch (...) {
+                    return fail(h, BISBM_ERR_STATE, "temperature table: out of host memory");
+                }
+                if (int rc = upload_table(sl.T, p.t_base, sl.zero_after)) return rc;
+            }
             sweeps_left -= now;
+            sweeps_done += now;
         }
+        first = false;
         uint32_t depth = max_depth;
         if (max_depth >= 2u) {
             uint32_t best = 0;
             for (uint32_t d = 1; d <= max_depth; ++d)
                 if (h->pass_speed[d] > h->pass_speed[best] || best == 0) best = h->pass_speed[d] > 0 ? d : best;
             // not tried yet: on small graphs the deepest first (there it won in every regime measured, and a call that cannot
-            // be split -- a cooling schedule, an early stop in reach -- runs its one launch with the first choice); on large ones
+            // be split -- an early stop in reach -- runs its one launch with the first choice); on large ones
             // the shallowest first (from a random start it is the faster one, and the next launches look further)
             if (h->n <= 100000) {
                 for (uint32_t d = 1; d <= max_depth; ++d)
@@ -830,16 +970,19 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
         else
             HIPCHK(h, launch_sweep(p, h->rng_mode, lds, h->stream));
         HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+        if (tab_segments && sweeps_left > 0) start_slice(sweeps_done, slice_sweeps(sweeps_left));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         float ms = 0;
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
         ms_sum += ms;
         HIPCHK(h, hipMemcpy(sc.data(), h->d_scalars, sizeof(ChainScalars) * h->n_chains, hipMemcpyDeviceToHost));
         uint64_t upd = 0;
+        bool all_stopped = true;
         for (uint32_t c = 0; c < h->n_chains; ++c) {
             acc_sum[c] += sc[c].last_accepted;
             sweeps_sum[c] += sc[c].last_sweeps;
             upd += sc[c].last_sweeps * h->n;
+            all_stopped = all_stopped && sc[c].stopped != 0;
         }
         updates += upd;
         if (max_depth >= 2u && ms > 0.05f && upd > 0) {
@@ -849,6 +992,10 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
                 fprintf(stderr, "[bisbm passes] depth %u: %.3e updates/ms (two %.3e, four %.3e, eight %.3e)\n", depth, speed, h->pass_speed[1],
                         h->pass_speed[2], h->pass_speed[3]);
         }
+        if (segmented && fast && all_stopped) {  // every chain has returned (:96-98)
+            if (next_slice.valid()) next_slice.wait();
+            break;
+        }
     }
     const float ms = (float)ms_sum;
     h->last_kernel_ms = ms_sum;
@@ -856,7 +1003,8 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
         for (uint32_t c = 0; c < h->n_chains; ++c) {
             sc[c].last_accepted = acc_sum[c];
             sc[c].last_sweeps = sweeps_sum[c];
-            sc[c].last_rate = (double)acc_sum[c] / (double)duration_steps;  // :100
+            sc[c].last_rate = (fast && sc[c].stopped) ? (double)acc_sum[c] / (double)(sweeps_sum[c] * h->n)  // :97
+                                                      : (double)acc_sum[c] / (double)duration_steps;          // :100
         }
         HIPCHK(h, hipMemcpy(h->d_scalars, sc.data(), sizeof(ChainScalars) * h->n_chains, hipMemcpyHostToDevice));
     }
@@ -890,6 +1038,13 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
 int bisbm_get_memberships(bisbm_handle h, uint32_t chain, uint32_t* labels_out) {
     if (!h) return BISBM_ERR_INVALID_ARG;
     if (!labels_out || chain >= h->n_chains) return fail(h, BISBM_ERR_INVALID_ARG, "bad chain or NULL output");
+    if (!h->devs.empty()) {
+        uint32_t local;
+        bisbm_engine* d = h->devs[dev_of_chain(h, chain, &local)];
+        const int rc = bisbm_get_memberships(d, local, labels_out);
+        if (rc) h->err = d->err;
+        return rc;
+    }
     if (!h->groups.empty()) {
         bisbm_engine* g = h->groups[h->where[chain].first];
         const int rc = bisbm_get_memberships(g, h->where[chain].second, labels_out);
@@ -906,6 +1061,13 @@ int bisbm_get_memberships(bisbm_handle h, uint32_t chain, uint32_t* labels_out) 
 int bisbm_get_block_state(bisbm_handle h, uint32_t chain, int32_t* m, int32_t* m_r, int32_t* n_r, uint32_t* eta) {
     if (!h) return BISBM_ERR_INVALID_ARG;
     if (chain >= h->n_chains) return fail(h, BISBM_ERR_INVALID_ARG, "chain out of range");
+    if (!h->devs.empty()) {
+        uint32_t local;
+        bisbm_engine* d = h->devs[dev_of_chain(h, chain, &local)];
+        const int rc = bisbm_get_block_state(d, local, m, m_r, n_r, eta);
+        if (rc) h->err = d->err;
+        return rc;
+    }
     if (!h->groups.empty()) {  // (array sizes follow the chain's own shape: bisbm_get_ka_kb_chain)
         bisbm_engine* g = h->groups[h->where[chain].first];
         const int rc = bisbm_get_block_state(g, h->where[chain].second, m, m_r, n_r, eta);
@@ -934,6 +1096,7 @@ int bisbm_get_block_state(bisbm_handle h, uint32_t chain, int32_t* m, int32_t* m
 
 int bisbm_get_cum_dS(bisbm_handle h, double* out) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    if (h && !h->devs.empty() && out) return on_devices(h, [&](bisbm_engine* d, size_t i) { return bisbm_get_cum_dS(d, out + h->dev_first[i]); });
     if (!out) return fail(h, BISBM_ERR_INVALID_ARG, "out is NULL");
     if (!h->groups.empty()) return gather_groups<double>(h, out, [](bisbm_engine* g, double* o) { return bisbm_get_cum_dS(g, o); });
     HIPCHK(h, hipSetDevice(h->device));
@@ -946,6 +1109,10 @@ int bisbm_get_cum_dS(bisbm_handle h, double* out) {
 
 int bisbm_get_last_counts(bisbm_handle h, uint64_t* accepted, uint64_t* sweeps) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!h->devs.empty())
+        return on_devices(h, [&](bisbm_engine* d, size_t i) {
+            return bisbm_get_last_counts(d, accepted ? accepted + h->dev_first[i] : nullptr, sweeps ? sweeps + h->dev_first[i] : nullptr);
+        });
     if (!h->groups.empty()) {
         const int rc = gather_groups<uint64_t>(h, accepted, [](bisbm_engine* g, uint64_t* o) { return bisbm_get_last_counts(g, o, nullptr); });
         return rc ? rc : gather_groups<uint64_t>(h, sweeps, [](bisbm_engine* g, uint64_t* o) { return bisbm_get_last_counts(g, nullptr, o); });
@@ -964,6 +1131,7 @@ int bisbm_get_last_counts(bisbm_handle h, uint64_t* accepted, uint64_t* sweeps) 
 int bisbm_entropy(bisbm_handle h, double* out) {
     if (!h) return BISBM_ERR_INVALID_ARG;
     if (!out) return fail(h, BISBM_ERR_INVALID_ARG, "out is NULL");
+    if (!h->devs.empty()) return on_devices(h, [&](bisbm_engine* d, size_t i) { return bisbm_entropy(d, out + h->dev_first[i]); });
     if (!h->groups.empty()) return gather_groups<double>(h, out, [](bisbm_engine* g, double* o) { return bisbm_entropy(g, o); });
     if (!h->state_ready) return fail(h, BISBM_ERR_STATE, "block state not built yet");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1004,11 +1172,12 @@ int bisbm_entropy(bisbm_handle h, double* out) {
 
 int bisbm_marginals_reset(bisbm_handle h) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!h->devs.empty()) return on_devices(h, [](bisbm_engine* d, size_t) { return bisbm_marginals_reset(d); });
     if (!h->groups.empty() && !common_shape(h))
         return fail(h, BISBM_ERR_STATE, "the chains of this handle have different block counts: no common marginal histogram");
     HIPCHK(h, hipSetDevice(h->device));
     const uint32_t kmax = std::max(h->ka, h->kb);
-    const size_t cnt = (size_t)h->n * kmax;
+    const size_t cnt = (size_t)std::max<uint64_t>(h->n, h->counts_rows) * kmax;  // (rows past n stay zero: see DevicePool)
     if (h->d_counts && h->counts_kmax < kmax) {
         (void)hipFree(h->d_counts);
         h->d_counts = nullptr;
@@ -1025,6 +1194,11 @@ int bisbm_marginals_reset(bisbm_handle h) {
 
 int bisbm_marginals_accumulate(bisbm_handle h, uint32_t* device_counts) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!h->devs.empty()) {
+        if (device_counts) return fail(h, BISBM_ERR_UNSUPPORTED, "a handle over several devices accumulates into its own buffers (device_counts must be NULL); bisbm_marginals_map pools them");
+        if (int rc = multi_common_shape(h, nullptr, nullptr)) return rc;
+        return on_devices(h, [](bisbm_engine* d, size_t) { return bisbm_marginals_accumulate(d, nullptr); });
+    }
     if (!h->groups.empty() && !common_shape(h))
         return fail(h, BISBM_ERR_STATE, "the chains of this handle have different block counts: no common marginal histogram");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1056,6 +1230,7 @@ int bisbm_marginals_accumulate(bisbm_handle h, uint32_t* device_counts) {
 int bisbm_marginals_get(bisbm_handle h, uint32_t* counts_out) {
     if (!h) return BISBM_ERR_INVALID_ARG;
     if (!counts_out) return fail(h, BISBM_ERR_INVALID_ARG, "counts_out is NULL");
+    if (!h->devs.empty()) return multi_marginals_get(h, counts_out);
     if (!h->groups.empty() && !common_shape(h))
         return fail(h, BISBM_ERR_STATE, "the chains of this handle have different block counts: no common marginal histogram");
     if (!h->d_counts) return fail(h, BISBM_ERR_STATE, "no internal marginal buffer yet");
@@ -1070,6 +1245,7 @@ int bisbm_marginals_get(bisbm_handle h, uint32_t* counts_out) {
 
 int bisbm_get_ka_kb(bisbm_handle h, uint32_t* ka, uint32_t* kb) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!h->devs.empty()) return multi_common_shape(h, ka, kb);
     if (!h->groups.empty() && !common_shape(h))
         return fail(h, BISBM_ERR_STATE, "the chains of this handle have different block counts: ask per chain (bisbm_get_ka_kb_chain)");
     if (ka) *ka = h->ka;
@@ -1095,6 +1271,11 @@ int bisbm_last_sweep_timing(bisbm_handle h, double* kernel_ms, uint64_t* node_up
 
 int bisbm_debug_log_q(bisbm_handle h, const int32_t* n, const int32_t* k, size_t count, int fast, double* out) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!h->devs.empty()) {
+        const int rc = bisbm_debug_log_q(h->devs[0], n, k, count, fast, out);
+        if (rc) h->err = h->devs[0]->err;
+        return rc;
+    }
     if (!n || !k || !out) return fail(h, BISBM_ERR_INVALID_ARG, "NULL argument");
     if (count == 0) return BISBM_OK;
     HIPCHK(h, hipSetDevice(h->device));
@@ -1113,6 +1294,81 @@ int bisbm_debug_log_q(bisbm_handle h, const int32_t* n, const int32_t* k, size_t
     (void)hipFree(dk);
     (void)hipFree(dout);
     return BISBM_OK;
+}
+
+
+int bisbm_create_multi(bisbm_handle* out, uint64_t n, uint64_t na, uint64_t nb, const uint64_t* rowptr, const uint32_t* col,
+                       uint32_t ka, uint32_t kb, double epsilon, uint32_t n_chains, uint32_t first_chain_id, const int* devices,
+                       int n_devices, int rng_mode, uint64_t seed, uint64_t gen_seed) {
+    if (!out) return fail(nullptr, BISBM_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!devices || n_devices < 1) return fail(nullptr, BISBM_ERR_INVALID_ARG, "devices is NULL or empty");
+    if ((uint32_t)n_devices > n_chains) return fail(nullptr, BISBM_ERR_INVALID_ARG, "%d devices for %u chains: every device needs at least one chain", n_devices, n_chains);
+    std::unique_ptr<bisbm_engine> hp(new bisbm_engine());
+    bisbm_engine* h = hp.get();
+    const size_t nd = (size_t)n_devices;
+    h->device = devices[0];
+    h->n = n, h->na = na, h->nb = nb, h->ka = ka, h->kb = kb, h->K = ka + kb;
+    h->n_chains = n_chains, h->first_chain_id = first_chain_id, h->epsilon = epsilon, h->rng_mode = rng_mode, h->seed = seed, h->gen_seed = gen_seed;
+    h->counts_rows = (n + nd - 1) / nd * nd;  // node ranges of equal size for the reduce-scatter (rows past n stay zero)
+    // contiguous chain ranges, the first n_chains % n_devices devices one chain more (the split bench.py and
+    // distributed.shard_chains use)
+    h->devs.assign(nd, nullptr);
+    h->dev_first.assign(nd + 1, 0);
+    for (size_t i = 0; i < nd; ++i) h->dev_first[i + 1] = h->dev_first[i] + n_chains / (uint32_t)nd + (i < n_chains % nd ? 1u : 0u);
+    // the devices are set up side by side (graph upload, table upload); the host tables are built once and shared
+    std::vector<int> rcs(nd, BISBM_OK);
+    std::vector<std::string> errs(nd);
+    std::mutex err_mu;
+    {
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < nd; ++i)
+            th.emplace_back([&, i] {
+                bisbm_handle d = nullptr;
+                rcs[i] = bisbm_create(&d, n, na, nb, rowptr, col, ka, kb, epsilon, h->dev_first[i + 1] - h->dev_first[i],
+                                      first_chain_id + h->dev_first[i], devices[i], rng_mode, seed, gen_seed);
+                if (rcs[i]) {
+                    std::lock_guard<std::mutex> lk(err_mu);  // (the message of a failed create is a process-wide string)
+                    errs[i] = g_create_error;
+                }
+                h->devs[i] = d;
+            });
+        for (auto& t : th) t.join();
+    }
+    for (size_t i = 0; i < nd; ++i)
+        if (rcs[i]) {
+            const int rc = rcs[i];
+            const std::string msg = "device " + std::to_string(devices[i]) + ": " + errs[i];
+            for (bisbm_engine*& d : h->devs)
+                if (d) {
+                    free_all(d);
+                    delete d;
+                    d = nullptr;
+                }
+            h->devs.clear();
+            return fail(nullptr, rc, "%s", msg.c_str());
+        }
+    for (bisbm_engine* d : h->devs) d->counts_rows = h->counts_rows;
+    h->num_edges = h->devs[0]->num_edges, h->nnz = h->devs[0]->nnz, h->maxdeg = h->devs[0]->maxdeg;
+    *out = hp.release();
+    return BISBM_OK;
+}
+
+int bisbm_device_count(bisbm_handle h, int* n_devices, int* devices, uint32_t* first_chain) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    const size_t nd = h->devs.empty() ? 1 : h->devs.size();
+    if (n_devices) *n_devices = (int)nd;
+    for (size_t i = 0; i < nd; ++i) {
+        if (devices) devices[i] = h->devs.empty() ? h->device : h->devs[i]->device;
+        if (first_chain) first_chain[i] = h->devs.empty() ? 0u : h->dev_first[i];
+    }
+    return BISBM_OK;
+}
+
+int bisbm_marginals_map(bisbm_handle h, uint32_t* labels_out) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!labels_out) return fail(h, BISBM_ERR_INVALID_ARG, "labels_out is NULL");
+    return h->devs.empty() ? single_marginals_map(h, labels_out) : multi_marginals_map(h, labels_out);
 }
 
 }  // extern "C"
@@ -1554,16 +1810,9 @@ int run_split(bisbm_engine* h, int type, int nm) {
                 }
             }
         };
-        const unsigned n_thr = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, std::thread::hardware_concurrency()), C / 4));
-        if (n_thr <= 1) {
-            for (size_t c = 0; c < C; ++c) eval_chain(c);
-        } else {  // chains are independent
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < n_thr; ++t)
-                th.emplace_back([&, t] {
-                    for (size_t c = t; c < C; c += n_thr) eval_chain(c);
-                });
-            for (auto& x : th) x.join();
+        if (!for_each_chain(C, eval_chain)) {  // chains are independent
+            cleanup();
+            return fail(h, BISBM_ERR_STATE, "agg_split: host-side evaluation failed (out of memory?)");
         }
     }
     std::vector<uint32_t> chosen(2 * C);
@@ -1730,18 +1979,9 @@ int run_merges(bisbm_engine* h, int which, int diff_a, int diff_b, int nm, std::
             store_mt(mc.gen, &mt_g[c * 624], sc[c].gen_idx);
         }
     };
-    {
-        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, std::thread::hardware_concurrency()), C / 4));
-        if (nt <= 1) {
-            for (size_t c = 0; c < C; ++c) one_chain(c);
-        } else {
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < nt; ++t)
-                th.emplace_back([&, t] {
-                    for (size_t c = t; c < C; c += nt) one_chain(c);
-                });
-            for (auto& x : th) x.join();
-        }
+    if (!for_each_chain(C, one_chain)) {
+        cleanup();
+        return fail(h, BISBM_ERR_STATE, "agg_merge: host-side selection failed (out of memory? a chain's merge state is K x K integers)");
     }
     for (size_t c = 0; c < C; ++c)
         if (rcs[c] != 0) {
@@ -1825,6 +2065,7 @@ bisbm_engine* new_group(bisbm_engine* root, uint32_t ka, uint32_t kb, uint32_t c
     for (int d = 0; d < 4; ++d) g->pass_speed[d] = 0;  // (another shape: measured afresh)
     g->d_rowptr = root->d_rowptr, g->d_col = root->d_col, g->d_lgamma = root->d_lgamma, g->d_logtab = root->d_logtab, g->d_q = root->d_q;
     g->tab = root->tab, g->q_stride = root->q_stride, g->ent_deg = root->ent_deg, g->ent_multi = root->ent_multi;
+    g->deg_count = root->deg_count;
     const size_t C = count, K = g->K, D = (size_t)g->maxdeg + 1;
     hipError_t e = hipStreamCreateWithFlags(&g->own_stream, hipStreamNonBlocking);
     g->stream = g->own_stream;
@@ -1940,9 +2181,23 @@ int merge_total_grouped(bisbm_engine* h, int diff, int nm) {
         if (rc == BISBM_OK) {
             next.push_back(g);
         } else if (rc == kDiverged) {
-            rc_all = split_by_shape(h, g, ends, next);
-            free_all(g);
-            delete g;
+            // the new groups first; `g` goes only once every one of its chains has a new home.  If that fails part-way (an
+            // allocation), the half-made groups are dropped and `g` stays in the handle -- its chains hold their merged labels
+            // under the old shape -- with its block state marked stale, so nothing addresses a chain that no longer exists
+            std::vector<bisbm_engine*> fresh;
+            rc_all = split_by_shape(h, g, ends, fresh);
+            if (rc_all == BISBM_OK) {
+                next.insert(next.end(), fresh.begin(), fresh.end());
+                free_all(g);
+                delete g;
+            } else {
+                for (bisbm_engine* f : fresh) {
+                    free_all(f);
+                    delete f;
+                }
+                g->state_ready = false;
+                next.push_back(g);
+            }
         } else {
             h->err = g->err;
             rc_all = rc;
@@ -1958,6 +2213,16 @@ int merge_total_grouped(bisbm_engine* h, int diff, int nm) {
 
 int bisbm_agg_merge(bisbm_handle h, int diff_a, int diff_b, int nm) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!h->devs.empty()) {
+        // (all or nothing, as for one device: a request a chain of some device cannot meet is refused before any device changes)
+        for (bisbm_engine* d : h->devs)
+            for (bisbm_engine* g : d->groups.empty() ? std::vector<bisbm_engine*>{d} : d->groups)
+                if (diff_a >= (int)g->ka || diff_b >= (int)g->kb)
+                    return fail(h, BISBM_ERR_STATE, "agg_merge(%d, %d): a chain of this handle has %u + %u blocks", diff_a, diff_b, g->ka, g->kb);
+        const int rc = on_devices(h, [&](bisbm_engine* d, size_t) { return bisbm_agg_merge(d, diff_a, diff_b, nm); });
+        (void)multi_common_shape(h, nullptr, nullptr);
+        return rc;
+    }
     if (!h->groups.empty()) {  // the same change of counts in every group: each keeps one shape
         for (bisbm_engine* g : h->groups)  // (all or nothing: a request no chain of some group can meet is refused before any group changes)
             if (diff_a >= (int)g->ka || diff_b >= (int)g->kb)
@@ -1976,12 +2241,26 @@ int bisbm_agg_merge(bisbm_handle h, int diff_a, int diff_b, int nm) {
 
 int bisbm_agg_merge_total(bisbm_handle h, int diff, int nm) {
     if (!h) return BISBM_ERR_INVALID_ARG;
+    if (!h->devs.empty()) {
+        for (bisbm_engine* d : h->devs)
+            for (bisbm_engine* g : d->groups.empty() ? std::vector<bisbm_engine*>{d} : d->groups)
+                if (diff > (int)g->ka + (int)g->kb - 2)
+                    return fail(h, BISBM_ERR_STATE, "agg_merge(%d): a chain of this handle has %u + %u blocks", diff, g->ka, g->kb);
+        const int rc = on_devices(h, [&](bisbm_engine* d, size_t) { return bisbm_agg_merge_total(d, diff, nm); });
+        (void)multi_common_shape(h, nullptr, nullptr);
+        return rc;
+    }
     return merge_total_grouped(h, diff, nm);
 }
 
 int bisbm_get_ka_kb_chain(bisbm_handle h, uint32_t chain, uint32_t* ka, uint32_t* kb) {
     if (!h) return BISBM_ERR_INVALID_ARG;
     if (chain >= h->n_chains) return fail(h, BISBM_ERR_INVALID_ARG, "chain out of range");
+    if (!h->devs.empty()) {
+        uint32_t local;
+        bisbm_engine* d = h->devs[dev_of_chain(h, chain, &local)];
+        return bisbm_get_ka_kb_chain(d, local, ka, kb);
+    }
     const bisbm_engine* e = h->groups.empty() ? h : h->groups[h->where[chain].first];
     if (ka) *ka = e->ka;
     if (kb) *kb = e->kb;

@@ -39,6 +39,7 @@
 // Diagnostic hooks (BISBM_STAMPS, BISBM_ABLATE) are compiled out of the product build.
 #include "bisbm_kernels.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <type_traits>
 
@@ -111,7 +112,9 @@ constexpr uint32_t kRowCap = 255;     // longest row the feeder walks (a k_v cou
     double name = (value);     \
     __asm__ volatile("" : "+v"(name))
 
-// EL: eta in LDS.  CT: constant schedule.  K32: both block counts <= 32 (five-level scans and sums).  K16 (with K32): both
+// EL: all of eta in LDS; otherwise a WINDOW of it: the rows of the phase's own type, p.eta_w consecutive degrees from
+// p.eta_lo_a / p.eta_lo_b on (chosen by the host to hold most nodes), swapped at the phase change -- steps of nodes whose degree
+// lies outside take the general path, which reads and writes those entries in HBM.  CT: constant schedule.  K32: both block counts <= 32 (five-level scans and sums).  K16 (with K32): both
 // block counts <= 16: four steps per pass in the four 16-lane rows of the wave (step_quad).  K8 (with K16): both <= 8: eight
 // steps per pass in groups of eight lanes (step_oct).
 template <bool EL, bool CT, bool K32, bool K16, bool K8>
@@ -120,12 +123,20 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     const uint32_t chain = blockIdx.x;
     if (chain >= p.n_chains) return;
     const uint32_t lane = threadIdx.x & 63u;
+    if (p.resume != 0u && p.scalars[chain].stopped != 0u) {  // a later launch of a call this chain has returned from (:96-98)
+        if (threadIdx.x == 0) {
+            p.scalars[chain].last_accepted = 0;
+            p.scalars[chain].last_sweeps = 0;
+        }
+        return;
+    }
     const uint32_t ka = p.ka, kb = p.kb, K = ka + kb, na = p.na, nb = p.nb;
     const uint32_t D = p.maxdeg + 1, S = kb | 1u;
     const uint32_t row_cap = p.maxdeg < kRowCap ? p.maxdeg : kRowCap;  // neighbours walked per row by the feeder
     // LDS layout, dword offsets
     const uint32_t o_mq = 0, o_eta = ka * S;
-    const uint32_t o_hist8 = o_eta + (EL ? K * D : 0u);                      // two buffers of k_v rows
+    const uint32_t eta_w = EL ? D : p.eta_w;                                  // degrees per row of eta in LDS
+    const uint32_t o_hist8 = o_eta + (EL ? K * D : (ka > kb ? ka : kb) * eta_w);  // two buffers of k_v rows
     const uint32_t o_hand = o_hist8 + 2 * kWave * (kHistStride / 4);         // two hand-off buffers, kHandWords x 64 dwords
     const uint32_t o_slow = o_hand + 2 * kHandWords * kWave;
     const uint32_t o_flag = o_slow + kWave;
@@ -185,7 +196,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
             for (uint32_t i = lane; i < K * D; i += kWave) eta_l[i] = eta_g[i];
         if (lane == 0) {
             *stop_flag = 0;
-            *below1_total = 0;
+            *below1_total = p.resume != 0u ? sc->stop_below1 : 0ull;
         }
     }
     // The stepping wave shares its SIMD with the feeder wave of another chain (four chains per CU): it is the
@@ -199,37 +210,36 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     __syncthreads();
     uint64_t sweeps_total = sc->sweeps_total;
 
-    auto eta_rd = [&](uint32_t idx) -> uint32_t { return EL ? eta_l[idx] : eta_g[idx]; };
-    auto eta_wr = [&](uint32_t idx, uint32_t val) {
-        if (EL)
-            eta_l[idx] = val;
-        else
-            eta_g[idx] = val;
-    };
-
     const double eps = p.epsilon;
     const double Kd = (double)K;
     const double epsK = eps * Kd;
     const uint32_t chain_gid = chain_gid_of(p, chain);
     const uint32_t n = p.n;
     const uint64_t all_sweeps = p.duration / n;
+    // A temperature so small that 1 / T overflows (the subnormal tail of an exponential schedule on its way to 0) acts like
+    // T = 0 in the reference's own arithmetic: -1 / T * dS is -inf, +inf or (dS = 0, r == s included) NaN, so a step is accepted
+    // exactly when dS < 0 (metropolis_hasting.cc:54-59).  Such a T is replaced by 0 here, once, where the temperatures are made.
+    // (A constant schedule cannot get there: its T is a float.)
     const double T_const = (double)p.kw0;  // CT: constant schedule (metropolis_hasting.cc:25-28)
     // the early-stop bookkeeping can only ever fire below T = 1, and only if steps_await can be reached within the call
     // (the counter starts at 0 and gains at most 1 per step) -- a scalar word, not a lane mask: one s_cmp to test
     // two steps per pass (step_pair): K <= 32 (a constant schedule at T = 0 takes the general step anyway);
     // p.pair_steps == 0 switches it off (A/B runs, tests); 2: four steps per pass where both block counts are <= 16
     const bool pair_mode = (uint32_t)__builtin_amdgcn_readfirstlane((K32 && (!CT || T_const > 0.) && p.pair_steps != 0) ? 1 : 0) != 0u;
+    // two steps per pass with more than 32 blocks of a type (step_pair64: two leaves per lane)
+    const bool pair64_mode = (uint32_t)__builtin_amdgcn_readfirstlane((!K32 && (!CT || T_const > 0.) && p.pair_steps != 0) ? 1 : 0) != 0u;
     const bool quad_mode = (uint32_t)__builtin_amdgcn_readfirstlane((K16 && !K8 && (!CT || T_const > 0.) && p.pair_steps > 1u) ? 1 : 0) != 0u;
     const bool oct_mode = (uint32_t)__builtin_amdgcn_readfirstlane((K8 && (!CT || T_const > 0.) && p.pair_steps > 2u) ? 1 : 0) != 0u;
     const uint32_t track_min =
-        (uint32_t)__builtin_amdgcn_readfirstlane(((!CT || T_const < 1.) && p.steps_await <= p.duration) ? 1 : 0);
+        (uint32_t)__builtin_amdgcn_readfirstlane(((!CT || T_const < 1.) && p.steps_await <= p.call_duration) ? 1 : 0);
     // constants of the hot step (log_q closed form, accept filter)
     BISBM_PIN(c_l2e, 0x1.71547652b82fep+0);        // log2(e)
     BISBM_PIN(c_tol, 1e-5);                        // accept filter margin
     LogQConsts lqc = log_q_consts();  // log_q closed form
     __asm__ volatile("" : "+v"(lqc.nc0l2e), "+v"(lqc.c1c0), "+v"(lqc.c1), "+v"(lqc.c2c0), "+v"(lqc.lfc));
     BISBM_PIN(c_576, 576.0);                       // 24^2: tier test k^2 > 576 n
-    BISBM_PIN(c_169, 169.0);                       // 13^2: tier test k^2 >= 169 n
+    double c_169 = 169.0;                          // 13^2: tier test k^2 >= 169 n
+    if (K32) __asm__ volatile("" : "+v"(c_169));   // (pinned like the others, except in the K > 32 variant: registers)
     uint64_t sweeps_done = 0;
     // Sum of accepted dS (blockmodel_t::entropy_) and accepted count: lane 0's copy is the value.  They are bumped
     // inside the lane-0 region of an accepted step (a vector add under the execution mask, no LDS round trip).
@@ -239,8 +249,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     // reached a new minimum, is only looked at when a sweep ends.  Kept as u = (steps with T < 1 so far) - (steps with
     // T < 1 before the step of the last minimum): the first count advances once per chunk, the second (and the minimum
     // itself) lives in lane 0's registers and is touched by accepted moves only -- a rejected step does nothing.
-    double emin_l0 = INFINITY;
-    unsigned long long mark_l0 = 0;
+    double emin_l0 = p.resume != 0u ? sc->stop_emin : INFINITY;
+    unsigned long long mark_l0 = p.resume != 0u ? sc->stop_mark : 0ull;
     double rate = 0.;
     bool stopped = false;
 #ifdef BISBM_STAMPS
@@ -249,7 +259,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
 #endif
 
     for (uint64_t sweep = 0; sweep < all_sweeps; ++sweep) {
-        const uint64_t sweep_step0 = (uint64_t)n * sweep;  // metropolis_hasting.cc:82
+        const uint64_t sweep_step0 = p.t_base + (uint64_t)n * sweep;  // metropolis_hasting.cc:82
 
         // One phase = every node of one type.  TB: the phase's nodes are type b.
         auto run_phase = [&](auto tb_tag) {
@@ -263,18 +273,57 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
             // 1 / (m_r[t] + eps K), lane t <-> opposite block t.  With epsilon = 0 the denominator is zero for idle lanes and
             // for blocks without edges; their k is zero, and 0 * finite * 0 keeps their leaves at zero (0 * inf would not)
             const double den_oth = mr_oth + epsK;
-            const double inv_oth = den_oth > 0. ? 1.0 / den_oth : 0.;
+            const double inv_blk = den_oth > 0. ? 1.0 / den_oth : 0.;  // lane <-> block (one copy per half / row / group below 33 blocks)
             // m[own block i][opposite block j] in the a x b quadrant
             auto mq_at = [&](uint32_t i_own, uint32_t j_oth) -> uint32_t {
                 return TB ? j_oth * S + i_own : i_own * S + j_oth;
             };
-            const double sign_tail = lb >= 8 ? 0. : ((lb < 2 || lb >= 6) ? -1. : 1.);
-            const double sign_q = lb >= 4 ? 0. : (lb < 2 ? -1. : 1.);
+            // eta[own block i][degree]: index into eta_l (hot paths: the degree is inside the window), and the accessors of
+            // the general path, which also serve the degrees outside it (from HBM)
+            const uint32_t eta_lo = EL ? 0u : (TB ? p.eta_lo_b : p.eta_lo_a);
+            auto eta_at = [&](uint32_t i_own, uint32_t deg) -> uint32_t {
+                return EL ? (own_base + i_own) * D + deg : i_own * eta_w + (deg - eta_lo);
+            };
+            auto eta_any_rd = [&](uint32_t i_own, uint32_t deg) -> uint32_t {
+                if (EL || deg - eta_lo < eta_w) return eta_l[eta_at(i_own, deg)];
+                return eta_g[(own_base + i_own) * D + deg];
+            };
+            auto eta_any_wr = [&](uint32_t i_own, uint32_t deg, uint32_t val) {
+                if (EL || deg - eta_lo < eta_w)
+                    eta_l[eta_at(i_own, deg)] = val;
+                else
+                    eta_g[(own_base + i_own) * D + deg] = val;
+            };
+            if (!EL && is_main) {  // the window of this phase's type: HBM -> LDS (written back when the phase ends)
+                for (uint32_t i = lane; i < k_own * eta_w; i += kWave) {
+                    const uint32_t row = i / eta_w, d = eta_lo + i % eta_w;
+                    eta_l[i] = d < D ? eta_g[(own_base + row) * D + d] : 0u;
+                }
+                wfence();
+            }
+            // step_pair64 (more than 32 blocks of a type, two steps per pass): lane l of a half holds the opposite-type blocks
+            // l and l + 32 (two leaves per lane, added first: level 32 of the summation tree) and, for the inverse CDF, the
+            // own-type blocks l and l + 32.  The K > 32 variant keeps 1 / (m_r[t] + eps K) for exactly these two blocks; the
+            // one-step paths pick theirs (lane <-> block) out of the pair.
+            const uint32_t lh = lane & 31u;
+            const double inv_lo = __hiloint2double(__builtin_amdgcn_ds_bpermute((int)(lh << 2), __double2hiint(inv_blk)),
+                                                   __builtin_amdgcn_ds_bpermute((int)(lh << 2), __double2loint(inv_blk)));
+            const double inv_hi = __hiloint2double(__builtin_amdgcn_ds_bpermute((int)((lh + 32u) << 2), __double2hiint(inv_blk)),
+                                                   __builtin_amdgcn_ds_bpermute((int)((lh + 32u) << 2), __double2loint(inv_blk)));
+            auto inv_oth_of_lane = [&]() -> double { return K32 ? inv_blk : (lane < 32u ? inv_lo : inv_hi); };
+            // the scalar terms of dS sit in leaves 0..7 (lgamma) / 0..3 (log_q) of a step's sum: lane pattern by the lane's
+            // position in its half / row / group (K > 32: in its half, for step_pair64)
+            const uint32_t ls = K32 ? lb : lh;
+            const double sign_tail = ls >= 8 ? 0. : ((ls < 2 || ls >= 6) ? -1. : 1.);
+            const double sign_q = ls >= 4 ? 0. : (ls < 2 ? -1. : 1.);
             // the one-step evaluations (step_general, step) sum lanes 0..31 or 0..63 as ONE step: only its first row carries
-            // the scalar terms (with four copies per wave, K <= 16, lanes 16..23 would add them a second time)
-            // (the other variants: the same registers as sign_tail / sign_q -- their one-step sums never reach a second copy)
-            const double sign_tail1 = K16 ? (lane < 8u ? sign_tail : 0.) : sign_tail;
-            const double sign_q1 = K16 ? (lane < 8u ? sign_q : 0.) : sign_q;
+            // the scalar terms (with several copies per wave -- K <= 16, or the two halves of the K > 32 variant -- the other
+            // copies would add them again).  K <= 16: registers of their own; K > 32: selected at the use (registers are
+            // scarce there); K <= 32: the same registers as sign_tail / sign_q.
+            const double sign_tail1_r = K16 ? (lane < 8u ? sign_tail : 0.) : sign_tail;
+            const double sign_q1_r = K16 ? (lane < 8u ? sign_q : 0.) : sign_q;
+            auto sign_tail1_of = [&]() -> double { return K32 ? sign_tail1_r : (lane < 32u ? sign_tail : 0.); };
+            auto sign_q1_of = [&]() -> double { return K32 ? sign_q1_r : (lane < 32u ? sign_q : 0.); };
             const int eoff_l = (lane & 7u) < 6 ? 1 : ((lane & 1u) ? 2 : 0);       // eta_r+1, eta_s+1, eta_r, eta_s+2
             const int dq_l = (lane & 2u) ? ((lane & 1u) ? 1 : -1) : 0;            // n_r - 1, n_s + 1 in lanes 2,3 (mod 4)
             const int dsgn_l = dq_l;                                              // -deg, +deg in the same lanes
@@ -286,6 +335,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
             order.init(phx_draw(p.seed, chain_gid, PHX_SWEEP_KEY, 2 * sweeps_total + (TB ? 1 : 0)), n_own);
             const uint32_t n_chunks = (n_own + kWave - 1) / kWave;
             const unsigned long long lanes_koth = __builtin_amdgcn_ballot_w64(lb < k_oth);  // both halves in the K <= 32 variants
+            const unsigned long long lanes_koth64_lo = __builtin_amdgcn_ballot_w64((lane & 31u) < k_oth);       // step_pair64: the lane's
+            const unsigned long long lanes_koth64_hi = __builtin_amdgcn_ballot_w64((lane & 31u) + 32u < k_oth);  // two opposite-type blocks
             const uint32_t node_other0 = TB ? 0u : na;  // some node of the opposite type: what idle slots of the walk load
 
             // ---- feeder wave: everything of chunk c that does not depend on the chain's block state ----
@@ -368,26 +419,34 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 const uint32_t cnt = (n_own - vi0) < (uint32_t)kWave ? (n_own - vi0) : (uint32_t)kWave;
                 const uint8_t* const hist8_cur = (const uint8_t*)(hist8_base + (c & 1u) * kWave * (kHistStride / 4));
                 const uint32_t* const hand = hand_base + (c & 1u) * kHandWords * kWave;
-                const uint32_t v_l = hand[0 * kWave + lane], beg_l = hand[1 * kWave + lane];
+                // Per-lane data of the chunk that lives through its steps: the node, the accept uniform, the packed inputs of the
+                // hot step (below).  Everything else the rare general step needs -- row begin, full degree, own and pivot label,
+                // the other three uniforms -- it reads back from the hand-off buffer / draws again itself (counter-based):
+                // some ten vector registers less across the step loop.
+                const uint32_t v_l = hand[0 * kWave + lane];
                 const uint32_t deg_l = hand[2 * kWave + lane], r_l = hand[3 * kWave + lane];
                 const int piv_l = (int)hand[4 * kWave + lane];
-                double ud_idx = 0., ud_R = 0., ud_tgt = 0., ud_acc = 0.;
-                uint32_t which_l = 0;
-                if (lane < cnt) {  // the four uniforms of step vi0 + lane (counter-based: any lane can draw them)
+                double ud_R = 0., ud_tgt = 0., ud_acc = 0.;
+                if (lane < cnt) {  // the uniforms of step vi0 + lane (counter-based: any lane can draw them)
                     const uint64_t gs = sweeps_total * (uint64_t)n + node_base + vi0 + lane;
                     const U4 A = phx_draw(p.seed, chain_gid, PHX_STEP_A, gs);
                     const U4 B = phx_draw(p.seed, chain_gid, PHX_STEP_B, gs);
-                    ud_idx = u53(A.x, A.y);
                     ud_R = u53(A.z, A.w);
                     ud_tgt = u53(B.x, B.y);
                     ud_acc = u53(B.z, B.w);
-                    which_l = (uint32_t)(ud_idx * (double)deg_l);
-                    if (which_l >= deg_l) which_l = deg_l ? deg_l - 1 : 0;
                 }
                 // the temperatures of the 64 steps (:84), lane = step: one table read or one pow / log per lane per chunk
                 double T_l = T_const;
-                if (!CT) T_l = temperature_of(p, sweep_step0 + node_base + vi0 + lane);
+                if (!CT) T_l = temperature_tabled(p, sweep_step0 + node_base + vi0 + lane);
                 const double invT_l = 1.0 / T_l;  // (T == 0: not used, the step is decided by the sign of dS)
+                if (!CT && invT_l == INFINITY) T_l = 0.;  // (see T_const)
+                // (the general step evaluates its temperature again -- a table read at a wave-uniform index -- instead of keeping
+                // the chunk's 64 temperatures alive through the step loop for it)
+                auto T_of_step = [&](uint32_t q) -> double {
+                    if (CT) return T_const;
+                    const double T = temperature_tabled(p, sweep_step0 + node_base + vi0 + q);
+                    return 1.0 / T == INFINITY ? 0. : T;
+                };
                 // The proposal's random part (blockmodel.cc:619-628) for all 64 steps at once, lane = step: the
                 // opposite type's labels and m_r are frozen during the phase, so the R test (:622-624) and the
                 // inverse-CDF target x do not depend on the moves made inside the chunk.  Bit 31 set: uniform
@@ -407,13 +466,19 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 const uint32_t tloc_l = ((uint32_t)piv_l - oth_base) & 63u;
                 const uint32_t rloc_l = r_l - own_base;
                 uint32_t prop_l = draw_target(__builtin_amdgcn_ds_bpermute((int)(tloc_l << 2), mr_oth), ud_R, ud_tgt);
+                // per-step inputs of the hot step: degree (<= 255 there), own block and pivot block in one word (one cross-lane move)
+                const uint32_t pack_l = (deg_l & 255u) | ((rloc_l & 63u) << 8) | (tloc_l << 16);
                 if (k_own == 1u || deg_l == 0u || deg_l > kRowCap || (CT && T_const == 0.)) prop_l |= 0x80000000u;
+                if (!EL && deg_l - eta_lo >= eta_w) prop_l |= 0x80000000u;  // eta[.][deg] is not in the LDS window
 
                 // anneal()'s bookkeeping, metropolis_hasting.cc:85-94, see emin_l0 above
                 const unsigned long long below1_mask =
                     track_min != 0u ? __builtin_amdgcn_ballot_w64(lane < cnt && T_l < 1.) : 0ull;
                 const unsigned long long below1_before = track_min != 0u ? *below1_total : 0ull;
-                auto new_minimum = [&](uint32_t q) {  // after the accepted move of step q (cum_l0 is updated)
+                // (:85-91 look at EVERY accepted step, also one whose proposal was r == s: that matters exactly once per call --
+                // the first accepted step finds entropy_min = +inf and sets it to the current sum whether or not it moved its
+                // node; afterwards an accepted r == s step finds the sum unchanged, hence not below the minimum)
+                auto new_minimum = [&](uint32_t q) {  // after accepted step q (cum_l0 is updated)
                     const unsigned long long before =
                         below1_before + (unsigned long long)__builtin_popcountll(below1_mask & ((1ull << q) - 1ull));
                     const bool better = cum_l0 < emin_l0;  // (:87-90)
@@ -426,8 +491,13 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
 
                 // ---- any step (all the rare cases included): the definition the hot path below specialises ----
                 auto step_general = [&](uint32_t q, double T) {
-                    const uint32_t v = readlane(v_l, q), deg = readlane(deg_l, q), r = readlane(r_l, q);
+                    auto handed = [&](uint32_t word) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)hand[word * kWave + q]); };
+                    const uint32_t v = handed(0), deg = handed(2), r = handed(3);
                     const uint32_t r_loc = r - own_base;
+                    // the step's four uniforms (:619-628, :57), drawn again here: wave-uniform values
+                    const uint64_t gs_q = sweeps_total * (uint64_t)n + node_base + vi0 + q;
+                    const U4 gA = phx_draw(p.seed, chain_gid, PHX_STEP_A, gs_q), gB = phx_draw(p.seed, chain_gid, PHX_STEP_B, gs_q);
+                    const double u_idx = u53(gA.x, gA.y), u_R = u53(gA.z, gA.w), u_tgt = u53(gB.x, gB.y), u_acc = u53(gB.z, gB.w);
                     // k_v counter of lane's block, row r of m, eta[r][deg] (unconditional reads, idle lanes masked
                     // afterwards: the k_v bytes past k_oth are zero, and the m reads past the quadrant stay inside
                     // the kernel's LDS allocation, see sweep_fast_lds_bytes)
@@ -438,17 +508,19 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t a_rt = mq_at(r_loc, lane);
                     const int32_t m_rt_raw = mq[a_rt];
                     const int32_t m_rt = lane < k_oth ? m_rt_raw : 0;
-                    const int eta_r = (int)eta_rd(r * D + deg);
-                    uint32_t t_piv = (uint32_t)readlane(piv_l, q);
+                    const int eta_r = (int)eta_any_rd(r_loc, deg);
+                    uint32_t t_piv = handed(4);
                     if (deg > kRowCap) {  // rows the feeder does not walk: straight from HBM
-                        const uint32_t beg = readlane(beg_l, q);
+                        const uint32_t beg = handed(1);
+                        uint32_t which = (uint32_t)(u_idx * (double)deg);  // pivot neighbour, blockmodel.cc:619
+                        if (which >= deg) which = deg - 1;
                         slow_hist[lane] = 0;
                         wfence();
                         for (uint32_t j = lane; j < deg; j += kWave)
                             atomicAdd(&slow_hist[(int)labels[p.col[beg + j]] - (int)oth_base], 1);
                         wfence();
                         k = lane < k_oth ? slow_hist[lane] : 0;
-                        t_piv = labels[p.col[beg + readlane(which_l, q)]];
+                        t_piv = labels[p.col[beg + which]];
                     }
                     // column t of m over v's own type; lanes >= k_own read past it and are ignored by the ballot
                     const int w_piv = mq[mq_at(lane, t_piv - oth_base)];
@@ -458,11 +530,10 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     if (k_own == 1) {
                         s = r;
                     } else if (deg == 0) {
-                        s = (uint32_t)(readlane(ud_idx, q) * Kd);
+                        s = (uint32_t)(u_idx * Kd);
                         if (s >= K) s = K - 1;
                     } else {
-                        const uint32_t prop =
-                            draw_target(readlane(mr_oth, t_piv - oth_base), readlane(ud_R, q), readlane(ud_tgt, q));
+                        const uint32_t prop = draw_target(readlane(mr_oth, t_piv - oth_base), u_R, u_tgt);
                         if ((int32_t)prop < 0) {
                             s = prop & 0x7fffffffu;
                         } else {  // integer inverse CDF over column m[.][t] restricted to v's own type (:627-628)
@@ -483,7 +554,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t a_st = mq_at(s_loc, lane);
                     const int32_t m_st_raw = mq[a_st];
                     const int32_t m_st = lane < k_oth ? m_st_raw : 0;
-                    const int eta_s = (int)eta_rd(s_eff * D + deg);
+                    const int eta_s = (int)eta_any_rd(s_loc, deg);
                     const int m0r = readlane(mr_own, r_loc);
                     const int m0s = readlane(mr_own, s_loc);
                     const int n_r_r = readlane(nr_own, r_loc), n_r_s = readlane(nr_own, s_loc);
@@ -504,14 +575,13 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double L3 = tab_at(tab.lg, (uint32_t)(m_rt + 1) - kk);
                     const double L4 = tab_at(tab.lg, (uint32_t)(m_st + 1) + kk);
                     // Hastings sums.  k == 0 lanes give exact zeros (0 * x = +0, identical table entries cancel).
-                    const double a0 = k * (m_st + eps) * inv_oth;
-                    const double a1 = k * (m_rt - k + eps) * inv_oth;
+                    const double a0 = k * (m_st + eps) * inv_oth_of_lane();
+                    const double a1 = k * (m_rt - k + eps) * inv_oth_of_lane();
                     double accu0, accu1;
                     if (k_oth <= 32u) {
                         butterfly_pair32(a0, a1, accu0, accu1);
                     } else {
-                        accu0 = butterfly_sum(a0);
-                        accu1 = butterfly_sum(a1);
+                        butterfly_pair64(a0, a1, accu0, accu1);
                     }
                     if (deg == 0) accu0 = accu1 = 1.;
                     const double lq = log_q<true>(tab, qn, qk, logn);
@@ -520,15 +590,15 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     // (sign_tail: -lg(m0r+1) -lg(m0s+1) +lg(m1r+1) +lg(m1s+1) +lg(eta_r+1) +lg(eta_s+1) -lg(eta_r)
                     // -lg(eta_s+2), zero from lane 8 on; sign_q: -,-,+,+, zero from lane 4 on.  x * (+-1) is exact and
                     // idle lanes add a zero: the table values are finite)
-                    d = d + tail_lg * sign_tail1;
-                    d = d + lq * sign_q1;
+                    d = d + tail_lg * sign_tail1_of();
+                    d = d + lq * sign_q1_of();
                     double dS = k_oth <= 32u ? butterfly_sum_low32(d) : butterfly_sum(d);
                     // accept (:47-61): T == 0: dS < 0;  else u < exp(-dS/T) accu1/accu0
                     bool accept;
                     if (T == 0.)
                         accept = dS < 0;
                     else
-                        accept = less_than_scaled_exp(readlane(ud_acc, q) * accu0, accu1, -dS * (1.0 / T));
+                        accept = less_than_scaled_exp(u_acc * accu0, accu1, -dS * (1.0 / T));
                     if (same) {
                         accept = (T != 0.);
                         dS = 0.;
@@ -541,8 +611,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     if (ok && !same) {
                         wfence();
                         if (lane == 0) {
-                            eta_wr(r * D + deg, (uint32_t)(eta_r - 1));
-                            eta_wr(s * D + deg, (uint32_t)(eta_s + 1));
+                            eta_any_wr(r_loc, deg, (uint32_t)(eta_r - 1));
+                            eta_any_wr(s_loc, deg, (uint32_t)(eta_s + 1));
                             labels[v] = (uint8_t)s;
                         }
                         mr_own += (lb == s_loc ? ideg : 0) - (lb == r_loc ? ideg : 0);
@@ -554,6 +624,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         if (lane == 0) cum_l0 += dS;  // :500
                         wfence();
                         if (track_min != 0u) new_minimum(q);
+                    } else if (ok && track_min != 0u) {
+                        new_minimum(q);  // an accepted r == s step (see new_minimum)
                     }
                     book(ok, T);
                 };
@@ -575,8 +647,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         step_general(q, T);
                         return;
                     }
-                    const uint32_t deg = readlane(deg_l, q), r_loc = readlane(rloc_l, q);
-                    const uint32_t t_loc = readlane(tloc_l, q);
+                    const uint32_t pack = readlane(pack_l, q);
+                    const uint32_t deg = pack & 255u, r_loc = (pack >> 8) & 63u, t_loc = pack >> 16;
                     // early LDS reads: k_v counter of lane's block, row r of m, column t of m over v's own type
                     const int k = (int)hist8_cur[q * kHistStride + lane];
                     const uint32_t a_rt = mq_at(r_loc, lane);
@@ -605,14 +677,16 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     if (s_loc == r_loc) {  // r == s: dS = 0, accepted as is unless T == 0; nothing changes (:109-112, :49-50)
                         const bool ok = n_r_r != 1 && (CT || T != 0.);
                         if (ok && lane == 0) acc_l0 += 1;
+                        if constexpr (TM)
+                            if (ok) new_minimum(q);
                         return;
                     }
                     const uint32_t r = own_base + r_loc, s = own_base + s_loc;
                     const int ideg = (int)deg;
                     const uint32_t a_st = mq_at(s_loc, lane);
                     const int32_t m_st_raw = mq[a_st];
-                    const int eta_r = (int)eta_rd(r * D + deg);
-                    const int eta_s = (int)eta_rd(s * D + deg);
+                    const int eta_r = (int)eta_l[eta_at(r_loc, deg)];
+                    const int eta_s = (int)eta_l[eta_at(s_loc, deg)];
                     const int32_t m_st = m_st_raw & kmask;
                     const int m0r = readlane(mr_own, r_loc);
                     const int m0s = readlane(mr_own, s_loc);
@@ -631,14 +705,13 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     FSTAMP_STEP(3);
                     // Hastings sums: on-chip data only, they run while the table gathers are in flight.
                     // k == 0 lanes give exact zeros (0 * x = +0, identical table entries cancel).
-                    const double a0 = k * (m_st + eps) * inv_oth;
-                    const double a1 = k * (m_rt - k + eps) * inv_oth;
+                    const double a0 = k * (m_st + eps) * inv_oth_of_lane();
+                    const double a1 = k * (m_rt - k + eps) * inv_oth_of_lane();
                     double accu0, accu1;
                     if (K32) {
                         butterfly_pair32(a0, a1, accu0, accu1);
                     } else {
-                        accu0 = butterfly_sum(a0);
-                        accu1 = butterfly_sum(a1);
+                        butterfly_pair64(a0, a1, accu0, accu1);
                     }
                     FSTAMP_STEP(4);
                     // log_q of the four (n, k) pairs, one per lane (mod 4).  Above the table, tier u = k / sqrt(n) > 24
@@ -676,8 +749,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     }
                     FSTAMP_STEP(5);
                     double d = (L1 + L2) - (L3 + L4);
-                    d = d + tail_lg * sign_tail1;  // scalar terms folded into leaves 0..7 / 0..3, see step_general
-                    d = d + lq * sign_q1;
+                    d = d + tail_lg * sign_tail1_of();  // scalar terms folded into leaves 0..7 / 0..3, see step_general
+                    d = d + lq * sign_q1_of();
                     const double dS = K32 ? butterfly_sum_low32(d) : butterfly_sum(d);
                     FSTAMP_STEP(6);
                     if (!CT && T == 0.) {  // the greedy tail of a cooling schedule (:49-50): dS < 0 decides
@@ -700,8 +773,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t v = readlane(v_l, q);
                     wfence();
                     if (lane == 0) {
-                        eta_wr(r * D + deg, (uint32_t)(eta_r - 1));
-                        eta_wr(s * D + deg, (uint32_t)(eta_s + 1));
+                        eta_l[eta_at(r_loc, deg)] = (uint32_t)(eta_r - 1);
+                        eta_l[eta_at(s_loc, deg)] = (uint32_t)(eta_s + 1);
                         labels[v] = (uint8_t)s;
                         cum_l0 += dS;  // :500
                         acc_l0 += 1;
@@ -731,8 +804,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 // bench workload: the second step stands in ~80 % of the passes, 1.8 steps per pass).
                 const uint32_t half = lane >> 5;
                 uint32_t acc_chunk = 0;  // accepted steps of the chunk's pair passes (a scalar word; added to acc_l0 per chunk)
-                // per-step inputs of the pair pass: degree, own block and pivot block in one word (one cross-lane move)
-                const uint32_t pack_l = (deg_l & 255u) | ((rloc_l & 63u) << 8) | (tloc_l << 16);
                 // q: first step of the pass; pairable: 1 = lanes 32..63 evaluate step q + 1, 0 = nothing to pair with
                 // (last step of the chunk, or a step that needs the general path next): both halves evaluate step q
                 // (cooling schedules: the temperature is the lane's own step's; steps at T = 0 are decided by the sign of dS)
@@ -783,6 +854,10 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     FSTAMP_STEP(2);
                     if ((selfA & selfB) != 0u) {  // both r == s: nothing changes (:109-112)
                         acc_chunk += (liveA & warmA) + (liveB & warmB);
+                        if constexpr (TM) {
+                            if ((liveA & warmA) != 0u) new_minimum(q);
+                            if ((liveB & warmB) != 0u) new_minimum(qB);
+                        }
                         return 1u + pairable;
                     }
                     // Would step q, if it moves its node, touch what step q + 1 read?  (block sets as bit masks)
@@ -800,8 +875,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
                     const uint32_t a_st = mq_at(s_loc, lb);
                     const int32_t m_st_raw = mq[a_st];
-                    const uint32_t e_idx = (own_base + idx_l) * D + deg;
-                    const int ee = (int)eta_rd(e_idx);
+                    const uint32_t e_idx = eta_at(idx_l, deg);
+                    const int ee = (int)eta_l[e_idx];
                     const int mm = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), mr_own);
                     const int nn = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), nr_own);
                     const int32_t m_st = m_st_raw & kmask;
@@ -814,8 +889,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double L2 = tab_at(tab.lg, (uint32_t)(m_st + 1));
                     const double L4 = tab_at(tab.lg, (uint32_t)(m_st + 1) + kk);
                     FSTAMP_STEP(3);
-                    const double a0 = k * (m_st + eps) * inv_oth;
-                    const double a1 = k * (m_rt - k + eps) * inv_oth;
+                    const double a0 = k * (m_st + eps) * inv_blk;
+                    const double a1 = k * (m_rt - k + eps) * inv_blk;
                     const double accu0 = butterfly_rows32(a0);  // lanes 16..31: step q, lanes 48..63: step q + 1
                     const double accu1 = butterfly_rows32(a1);
                     FSTAMP_STEP(4);
@@ -880,7 +955,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t chB = stands & (flags >> 2) & yesB;
                     const uint32_t okB = chB | (stands & (flags >> 3) & 1u);
                     acc_chunk += okA + okB;
-                    if ((chA | chB) != 0u) {
+                    if ((TM ? (okA | okB) : (chA | chB)) != 0u) {  // (with the early-stop bookkeeping on: every accepted step is looked at)
                         // ---- apply_mcmc_moves, blockmodel.cc:461-503, for the step(s) that move: their rows differ ----
                         const uint32_t mA = 0u - chA, mB = 0u - chB;  // all ones / zero
                         const int dS_A_lo = __builtin_amdgcn_readlane(__double2loint(dS), 31), dS_A_hi = __builtin_amdgcn_readlane(__double2hiint(dS), 31);
@@ -892,7 +967,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                             mq[a_st] = m_st_raw + k;
                         }
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000003000000030ull))  // lanes 4, 5: eta_r - 1, eta_s + 1
-                            eta_wr(e_idx, (uint32_t)(ee + ((int)(lb & 1u) * 2 - 1)));
+                            eta_l[e_idx] = (uint32_t)(ee + ((int)(lb & 1u) * 2 - 1));
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000000100000001ull)) labels[v] = (uint8_t)(own_base + s_loc);
                         const int dlA = (int)min(lb ^ r_locA, 1u) - (int)min(lb ^ s_locA, 1u);  // +1 on lane s, -1 on lane r
                         const int dlB = (int)min(lb ^ r_locB, 1u) - (int)min(lb ^ s_locB, 1u);
@@ -901,13 +976,187 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         // :500, in step order; a step that does not move adds +0.0 (x + 0.0 is x: the running sum is never -0.0)
                         cum_l0 += __hiloint2double(dS_A_hi & (int)mA, dS_A_lo & (int)mA);
                         if constexpr (TM)
-                            if (chA) new_minimum(q);  // (:86-90, after step q's move and before step q + 1's)
+                            if (okA) new_minimum(q);  // (:86-90, after step q's move and before step q + 1's)
                         cum_l0 += __hiloint2double(dS_B_hi & (int)mB, dS_B_lo & (int)mB);
                         if constexpr (TM)
-                            if (chB) new_minimum(qB);
+                            if (okB) new_minimum(qB);
                         wfence();
                     }
                     FSTAMP_STEP(8);
+                    return 1u + stands;
+                };
+
+                // ---- two steps per pass with more than 32 blocks of a type (the K > 32 variant) ----
+                // step_pair with TWO leaves per lane: lane l of a half (lower half: step q, upper half: step q + 1) holds the
+                // opposite-type blocks l and l + 32 -- their k, their entries of rows r and s, their table gathers, their leaves of
+                // the three sums, added first (level 32 of the summation tree, bisbm_device.hpp) -- and, for the inverse CDF,
+                // entries l and l + 32 of column t.  m_r / n_r sit one block per lane across the whole wave and are read by lane
+                // index.  The stand rule, the verdict logic and the writes are step_pair's (block sets as 64-bit masks).
+                                auto step_pair64 = [&](auto tm, uint32_t q, uint32_t pairable) -> uint32_t {
+                    constexpr bool TM = decltype(tm)::value;
+                    const uint32_t qB = q + pairable;
+                    const uint32_t qs = q + (half & (0u - pairable));
+                    const int sel = (int)(qs << 2);
+                    const uint32_t prop = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)prop_l);
+                    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)v_l);
+                    const double u_acc = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(ud_acc)),
+                                                          __builtin_amdgcn_ds_bpermute(sel, __double2loint(ud_acc)));
+                    const uint32_t packA = readlane(pack_l, q), packB = readlane(pack_l, qB);
+                    const uint32_t r_locA = (packA >> 8) & 63u, r_locB = (packB >> 8) & 63u;
+                    const uint32_t degA = packA & 255u, degB = packB & 255u, t_locA = packA >> 16, t_locB = packB >> 16;
+                    const uint32_t deg = (uint32_t)((int)degA + __mul24((int)half, (int)degB - (int)degA));
+                    const uint32_t r_loc = (uint32_t)((int)r_locA + __mul24((int)half, (int)r_locB - (int)r_locA));
+                    const uint32_t t_loc = (uint32_t)((int)t_locA + __mul24((int)half, (int)t_locB - (int)t_locA));
+                    const int k0 = (int)hist8_cur[qs * kHistStride + lh], k1 = (int)hist8_cur[qs * kHistStride + lh + 32u];
+                    const uint32_t a_rt0 = mq_at(r_loc, lh), a_rt1 = mq_at(r_loc, lh + 32u);
+                    const int32_t m_rt_raw0 = mq[a_rt0], m_rt_raw1 = mq[a_rt1];
+                    const int w0 = mq[mq_at(lh, t_loc)], w1 = mq[mq_at(lh + 32u, t_loc)];
+                    const uint32_t liveA = sflag((uint32_t)readlane(nr_own, r_locA) ^ 1u);
+                    const uint32_t liveB = smin((uint32_t)readlane(nr_own, r_locB) ^ 1u, pairable);
+                    const int32_t kmask0 = (0 - k0) >> 31, kmask1 = (0 - k1) >> 31;
+                    const int32_t m_rt0 = m_rt_raw0 & kmask0, m_rt1 = m_rt_raw1 & kmask1;
+                    const uint32_t kk0 = (uint32_t)k0, kk1 = (uint32_t)k1;
+                    const double L1_0 = tab_at(tab.lg, (uint32_t)(m_rt0 + 1)), L3_0 = tab_at(tab.lg, (uint32_t)(m_rt0 + 1) - kk0);
+                    const double L1_1 = tab_at(tab.lg, (uint32_t)(m_rt1 + 1)), L3_1 = tab_at(tab.lg, (uint32_t)(m_rt1 + 1) - kk1);
+                    __asm__ volatile("" ::: "memory");
+                    // inverse CDF per half over 64 own blocks (:627-628): the scan of blocks 0..31, its total, the scan of blocks
+                    // 32..63 on top.  (Lanes past k_own hold garbage; block k_own - 1 always qualifies, and with k_own <= 32 the first
+                    // hit lies in the lower scan, whose prefix sums up to it are clean.)
+                    const int scan0 = wave_inclusive_scan32(w0);
+                    const int tot = __builtin_amdgcn_ds_bpermute((int)(((lane & 32u) | 31u) << 2), scan0);
+                    const int scan1 = wave_inclusive_scan32(w1) + tot;
+                    const unsigned long long hit0 = __builtin_amdgcn_ballot_w64((uint32_t)scan0 > prop);
+                    const unsigned long long hit1 = __builtin_amdgcn_ballot_w64((uint32_t)scan1 > prop);
+                    const unsigned long long hitsA = (hit0 & 0xffffffffull) | (hit1 << 32), hitsB = (hit0 >> 32) | (hit1 & 0xffffffff00000000ull);
+                    uint32_t fhA, fhB;
+                    __asm__("s_ff1_i32_b64 %0, %1" : "=s"(fhA) : "s"(hitsA));
+                    __asm__("s_ff1_i32_b64 %0, %1" : "=s"(fhB) : "s"(hitsB));
+                    const uint32_t s_locA = min(fhA, last_own), s_locB = min(fhB, last_own);
+                    const uint32_t selfA = 1u - sflag(s_locA ^ r_locA), selfB = 1u - sflag(s_locB ^ r_locB);
+                    const uint32_t warmA = CT ? 1u : ((uint32_t)(zeroT_mask >> q) & 1u) ^ 1u;
+                    const uint32_t warmB = CT ? 1u : ((uint32_t)(zeroT_mask >> qB) & 1u) ^ 1u;
+                    if ((selfA & selfB) != 0u) {  // both r == s: nothing changes (:109-112)
+                        acc_chunk += (liveA & warmA) + (liveB & warmB);
+                        if constexpr (TM) {
+                            if ((liveA & warmA) != 0u) new_minimum(q);
+                            if ((liveB & warmB) != 0u) new_minimum(qB);
+                        }
+                        return 1u + pairable;
+                    }
+                    // would step q, if it moves its node, touch what step q + 1 read?  (step_pair's rule on 64-bit block sets)
+                    const unsigned long long setA = (1ull << r_locA) | (1ull << s_locA), setB = (1ull << r_locB) | (1ull << s_locB);
+                    const uint32_t lo = min(r_locA, s_locA), hi = max(r_locA, s_locA);
+                    const unsigned long long between = ((1ull << hi) - 1ull) & ~((2ull << lo) - 1ull);
+                    // (lanes 0..31 hold step q's k: block t_locB is the lower or the upper leaf of lane t_locB & 31; selections
+                    // stay arithmetic on scalar words, see sflag)
+                    const uint32_t kA0 = readlane(kk0, t_locB & 31u), kA1 = readlane(kk1, t_locB & 31u);
+                    const uint32_t kAtB = kA0 + (t_locB >> 5) * (kA1 - kA0);
+                    const unsigned long long common = setA & setB;
+                    const uint32_t clash = sflag((uint32_t)common | (uint32_t)(common >> 32)) | ((uint32_t)((between >> s_locB) & 1ull) & sflag(kAtB));
+                    const uint32_t flags = (liveA & (selfA ^ 1u)) | ((liveA & selfA & warmA) << 1) | ((liveB & (selfB ^ 1u)) << 2) |
+                                           ((liveB & selfB & warmB) << 3) | (clash << 4);
+
+                    const uint32_t s_loc = (uint32_t)((int)s_locA + __mul24((int)half, (int)s_locB - (int)s_locA));
+                    const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
+                    const uint32_t a_st0 = mq_at(s_loc, lh), a_st1 = mq_at(s_loc, lh + 32u);
+                    const int32_t m_st_raw0 = mq[a_st0], m_st_raw1 = mq[a_st1];
+                    const uint32_t e_idx = eta_at(idx_l, deg);
+                    const int ee = (int)eta_l[e_idx];
+                    const int mm = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), mr_own);
+                    const int nn = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), nr_own);
+                    const int32_t m_st0 = m_st_raw0 & kmask0, m_st1 = m_st_raw1 & kmask1;
+                    const int ideg = (int)deg;
+                    const int qn = mm + __mul24(ideg, dsgn_l);        // m0r, m0s, m0r - deg, m0s + deg
+                    const uint32_t tail_idx = (uint32_t)((qn ^ ((qn ^ ee) & eta_mask_l)) + toff_l);
+                    const int qk = nn + dq_l;
+                    const double tail_lg = tab_at(tab.lg, tail_idx);
+                    const double logn = tab_at(tab.logtab, (uint32_t)qn);
+                    const double L2_0 = tab_at(tab.lg, (uint32_t)(m_st0 + 1)), L4_0 = tab_at(tab.lg, (uint32_t)(m_st0 + 1) + kk0);
+                    const double L2_1 = tab_at(tab.lg, (uint32_t)(m_st1 + 1)), L4_1 = tab_at(tab.lg, (uint32_t)(m_st1 + 1) + kk1);
+                    // the lane's two leaves of each sum, added first (level 32)
+                    const double a0 = k0 * (m_st0 + eps) * inv_lo + k1 * (m_st1 + eps) * inv_hi;
+                    const double a1 = k0 * (m_rt0 - k0 + eps) * inv_lo + k1 * (m_rt1 - k1 + eps) * inv_hi;
+                    const double accu0 = butterfly_rows32(a0);  // lanes 16..31: step q, lanes 48..63: step q + 1
+                    const double accu1 = butterfly_rows32(a1);
+                    double lq;
+                    {
+                        const int qk2 = qk < qn ? qk : qn;
+                        const double nd = (double)qn, kd = (double)qk2;
+                        const double k2 = kd * kd;
+                        const bool direct = qn > kQNmax && k2 > c_576 * nd;
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!direct) == 0, 1)) {
+                            double sq, rr;
+                            sqrt_rsqrt(nd, sq, rr);
+                            lq = log_q_closed(kd, sq, rr, logn, lqc);
+                        } else if (__builtin_amdgcn_ballot_w64(qn > kQNmax) == 0) {
+                            lq = log_q_table(tab, qn, qk2);
+                        } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= c_169 * nd)) == 0) {
+                            double sq, rr;
+                            sqrt_rsqrt(nd, sq, rr);
+                            lq = log_q_closed2(kd, sq, rr, logn, lqc);
+                        } else {  // (the converged tier for 8 <= u < 13 is not inlined here: registers; the out-of-line evaluation holds it)
+                            lq = log_q<true>(tab, qn, qk, logn);
+                        }
+                    }
+                    double d = (L1_0 + L2_0) - (L3_0 + L4_0);
+                    d = d + tail_lg * sign_tail;  // the scalar terms sit in leaves 0..7 / 0..3: the lane's lower leaf
+                    d = d + lq * sign_q;
+                    d = d + ((L1_1 + L2_1) - (L3_1 + L4_1));
+                    const double dS = butterfly_rows32(d);
+                    double invT = invT_const;
+                    if (!CT) invT = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(invT_l)),
+                                                     __builtin_amdgcn_ds_bpermute(sel, __double2loint(invT_l)));
+                    const double z = -dS * invT;
+                    const double est = accu1 * exp2_filter(z * c_l2e);
+                    const double lhs = u_acc * accu0;
+                    unsigned long long b_acc = __builtin_amdgcn_ballot_w64(lhs < est);
+                    unsigned long long b_far = __builtin_amdgcn_ballot_w64(fabs(lhs - est) > c_tol * est);
+                    if (!CT) {  // steps at T = 0: dS < 0 decides (:49-50)
+                        const unsigned long long cold = ((unsigned long long)(0u - (warmB ^ 1u)) << 32) | (0u - (warmA ^ 1u));
+                        const unsigned long long b_neg = __builtin_amdgcn_ballot_w64(dS < 0.);
+                        b_acc = (b_acc & ~cold) | (b_neg & cold);
+                        b_far |= cold;
+                    }
+                    if (__builtin_expect((((uint32_t)b_far & (uint32_t)(b_far >> 32)) >> 31) == 0u, 0)) {  // a verdict too close to call
+                        const unsigned long long exact = __builtin_amdgcn_ballot_w64(lhs < accu1 * exp(z));
+                        b_acc = (b_acc & b_far) | (exact & ~b_far);
+                    }
+                    const uint32_t yesA = (uint32_t)(b_acc >> 31) & 1u, yesB = (uint32_t)(b_acc >> 63) & 1u;
+                    const uint32_t chA = flags & yesA;
+                    const uint32_t okA = chA | ((flags >> 1) & 1u);
+                    const uint32_t stands = pairable & ((chA & (flags >> 4)) ^ 1u);
+                    const uint32_t chB = stands & (flags >> 2) & yesB;
+                    const uint32_t okB = chB | (stands & (flags >> 3) & 1u);
+                    acc_chunk += okA + okB;
+                    if ((TM ? (okA | okB) : (chA | chB)) != 0u) {
+                        const uint32_t mA = 0u - chA, mB = 0u - chB;
+                        const int dS_A_lo = __builtin_amdgcn_readlane(__double2loint(dS), 31), dS_A_hi = __builtin_amdgcn_readlane(__double2hiint(dS), 31);
+                        const int dS_B_lo = __builtin_amdgcn_readlane(__double2loint(dS), 63), dS_B_hi = __builtin_amdgcn_readlane(__double2hiint(dS), 63);
+                        const unsigned long long movers = ((unsigned long long)mB << 32) | mA;
+                        wfence();
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & lanes_koth64_lo)) {  // k == 0: rewrites the same values
+                            mq[a_rt0] = m_rt_raw0 - k0;
+                            mq[a_st0] = m_st_raw0 + k0;
+                        }
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & lanes_koth64_hi)) {
+                            mq[a_rt1] = m_rt_raw1 - k1;
+                            mq[a_st1] = m_st_raw1 + k1;
+                        }
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000003000000030ull))  // lanes 4, 5: eta_r - 1, eta_s + 1
+                            eta_l[e_idx] = (uint32_t)(ee + ((int)(lh & 1u) * 2 - 1));
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000000100000001ull)) labels[v] = (uint8_t)(own_base + s_loc);
+                        const int dlA = (int)min(lane ^ r_locA, 1u) - (int)min(lane ^ s_locA, 1u);  // +1 on lane s, -1 on lane r (lane <-> block)
+                        const int dlB = (int)min(lane ^ r_locB, 1u) - (int)min(lane ^ s_locB, 1u);
+                        mr_own += __mul24((int)(degA & mA), dlA) + __mul24((int)(degB & mB), dlB);
+                        nr_own += __mul24((int)chA, dlA) + __mul24((int)chB, dlB);
+                        cum_l0 += __hiloint2double(dS_A_hi & (int)mA, dS_A_lo & (int)mA);
+                        if constexpr (TM)
+                            if (okA) new_minimum(q);
+                        cum_l0 += __hiloint2double(dS_B_hi & (int)mB, dS_B_lo & (int)mB);
+                        if constexpr (TM)
+                            if (okB) new_minimum(qB);
+                        wfence();
+                    }
                     return 1u + stands;
                 };
 
@@ -954,6 +1203,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const unsigned long long b_selfok = __builtin_amdgcn_ballot_w64(valid && live && self && warm) & kRowRep;
                     if (b_can == 0ull) {  // every step of the pass is an r == s (or a vetoed one): nothing changes (:109-112)
                         acc_chunk += (uint32_t)__builtin_popcountll(b_selfok);
+                        if constexpr (TM)
+                            if (b_selfok != 0ull) new_minimum(q + ((uint32_t)__builtin_ctzll(b_selfok) >> 4));  // (the first accepted one; the sum does not change)
                         return nst;
                     }
                     // pairwise: would step i, if it moves its node, touch what step j read?  (lane 4 i + j, any row)
@@ -975,8 +1226,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
                     const uint32_t a_st = mq_at(s_loc, lb);
                     const int32_t m_st_raw = mq[a_st];
-                    const uint32_t e_idx = (own_base + idx_l) * D + deg;
-                    const int ee = (int)eta_rd(e_idx);
+                    const uint32_t e_idx = eta_at(idx_l, deg);
+                    const int ee = (int)eta_l[e_idx];
                     const int mm = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), mr_own);
                     const int nn = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), nr_own);
                     const int32_t m_st = m_st_raw & kmask;
@@ -988,8 +1239,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double logn = tab_at(tab.logtab, (uint32_t)qn);
                     const double L2 = tab_at(tab.lg, (uint32_t)(m_st + 1));
                     const double L4 = tab_at(tab.lg, (uint32_t)(m_st + 1) + kk);
-                    const double a0 = k * (m_st + eps) * inv_oth;
-                    const double a1 = k * (m_rt - k + eps) * inv_oth;
+                    const double a0 = k * (m_st + eps) * inv_blk;
+                    const double a1 = k * (m_rt - k + eps) * inv_blk;
                     const double accu0 = butterfly_rows16(a0);  // every lane of a row: the row's sum
                     const double accu1 = butterfly_rows16(a1);
                     double lq;
@@ -1057,7 +1308,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         moved = m0 | (m1 << 1) | (m2 << 2) | (m3 << 3);
                     }
                     acc_chunk += (uint32_t)__builtin_popcount(moved | (commit & selfok4));
-                    if (moved != 0u) {
+                    if ((TM ? (moved | (commit & selfok4)) : moved) != 0u) {
                         // ---- apply_mcmc_moves, blockmodel.cc:461-503, for the steps that move: their rows of m differ ----
                         unsigned long long movers = 0ull;
                         if (moved & 1u) movers |= 0x000000000000ffffull;
@@ -1070,7 +1321,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                             mq[a_st] = m_st_raw + k;
                         }
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0030003000300030ull))  // lanes 4, 5 of a row: eta_r - 1, eta_s + 1
-                            eta_wr(e_idx, (uint32_t)(ee + ((int)(lb & 1u) * 2 - 1)));
+                            eta_l[e_idx] = (uint32_t)(ee + ((int)(lb & 1u) * 2 - 1));
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0001000100010001ull)) labels[v] = (uint8_t)(own_base + s_loc);
                         // the register copies of m_r / n_r, sum dS (:500) and the early-stop bookkeeping, in step order
 #pragma unroll
@@ -1082,6 +1333,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                                 nr_own += dl;
                                 cum_l0 += readlane(dS, 16u * g + 15u);
                                 if constexpr (TM) new_minimum(q + g);
+                            } else if (TM && (((commit & selfok4) >> g) & 1u)) {
+                                new_minimum(q + g);  // an accepted r == s step (see new_minimum)
                             }
                         }
                         wfence();
@@ -1095,7 +1348,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     while (q < cnt) {
                         const uint32_t four = (uint32_t)(gen_mask >> q) & 0xfu;
                         if (__builtin_expect((four & 1u) != 0u, 0)) {
-                            step_general(q, CT ? T_const : readlane(T_l, q));
+                            step_general(q, T_of_step(q));
                             q += 1u;
                         } else {  // the steps up to the next one that needs the general path, or to the end of the chunk
                             const uint32_t nst = min(min((uint32_t)__builtin_ctz(four | 0x10u), 4u), cnt - q);
@@ -1143,6 +1396,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const unsigned long long b_selfok = __builtin_amdgcn_ballot_w64(valid && live && self && warm) & kGrpRep;
                     if (b_can == 0ull) {
                         acc_chunk += (uint32_t)__builtin_popcountll(b_selfok);
+                        if constexpr (TM)
+                            if (b_selfok != 0ull) new_minimum(q + ((uint32_t)__builtin_ctzll(b_selfok) >> 3));
                         return nst;
                     }
                     unsigned long long clash_bits;  // byte j, bit i: step i (earlier), if it moves, touches what step j read
@@ -1163,8 +1418,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);
                     const uint32_t a_st = mq_at(s_loc, lb);
                     const int32_t m_st_raw = mq[a_st];
-                    const uint32_t e_idx = (own_base + idx_l) * D + deg;
-                    const int ee = (int)eta_rd(e_idx);
+                    const uint32_t e_idx = eta_at(idx_l, deg);
+                    const int ee = (int)eta_l[e_idx];
                     const int mm = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), mr_own);
                     const int nn = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), nr_own);
                     const int32_t m_st = m_st_raw & kmask;
@@ -1176,8 +1431,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double logn = tab_at(tab.logtab, (uint32_t)qn);
                     const double L2 = tab_at(tab.lg, (uint32_t)(m_st + 1));
                     const double L4 = tab_at(tab.lg, (uint32_t)(m_st + 1) + kk);
-                    const double a0 = k * (m_st + eps) * inv_oth;
-                    const double a1 = k * (m_rt - k + eps) * inv_oth;
+                    const double a0 = k * (m_st + eps) * inv_blk;
+                    const double a1 = k * (m_rt - k + eps) * inv_blk;
                     const double accu0 = butterfly_groups8(a0);
                     const double accu1 = butterfly_groups8(a1);
                     double lq;
@@ -1234,7 +1489,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         moved |= (stands & (mv8 >> j) & 1u) << j;
                     }
                     acc_chunk += (uint32_t)__builtin_popcount(moved | (commit & selfok8));
-                    if (moved != 0u) {
+                    if ((TM ? (moved | (commit & selfok8)) : moved) != 0u) {
                         unsigned long long movers = 0ull;  // all eight lanes of every mover's group
 #pragma unroll
                         for (uint32_t g = 0; g < 8u; ++g)
@@ -1245,7 +1500,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                             mq[a_st] = m_st_raw + k;
                         }
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x3030303030303030ull))  // lanes 4, 5 of a group: eta_r - 1, eta_s + 1
-                            eta_wr(e_idx, (uint32_t)(ee + ((int)(lb & 1u) * 2 - 1)));
+                            eta_l[e_idx] = (uint32_t)(ee + ((int)(lb & 1u) * 2 - 1));
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0101010101010101ull)) labels[v] = (uint8_t)(own_base + s_loc);
 #pragma unroll
                         for (uint32_t g = 0; g < 8u; ++g) {
@@ -1256,6 +1511,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                                 nr_own += dl;
                                 cum_l0 += readlane(dS, 8u * g + 7u);
                                 if constexpr (TM) new_minimum(q + g);
+                            } else if (TM && (((commit & selfok8) >> g) & 1u)) {
+                                new_minimum(q + g);
                             }
                         }
                         wfence();
@@ -1269,7 +1526,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     while (q < cnt) {
                         const uint32_t eight = (uint32_t)(gen_mask >> q) & 0xffu;
                         if (__builtin_expect((eight & 1u) != 0u, 0)) {
-                            step_general(q, CT ? T_const : readlane(T_l, q));
+                            step_general(q, T_of_step(q));
                             q += 1u;
                         } else {
                             const uint32_t nst = min(min((uint32_t)__builtin_ctz(eight | 0x100u), 8u), cnt - q);
@@ -1286,15 +1543,22 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     while (q < cnt) {
                         const uint32_t two = (uint32_t)(gen_mask >> q) & 3u;
                         if (__builtin_expect((two & 1u) != 0u, 0)) {
-                            step_general(q, CT ? T_const : readlane(T_l, q));
+                            step_general(q, T_of_step(q));
                             q += 1u;
-                        } else {
+                        } else if (K32) {
                             q += step_pair(tm, q, ((two >> 1) ^ 1u) & sflag(cnt - 1u - q));
+                        } else {  // (one step per pass, BISBM_SINGLE_STEPS=1: a pass whose two halves evaluate the same step)
+                            q += step_pair64(tm, q, ((two >> 1) ^ 1u) & sflag(cnt - 1u - q) & (pair64_mode ? 1u : 0u));
                         }
                     }
                     acc_l0 += (unsigned long long)acc_chunk;
                 };
-                if (K8 && oct_mode) {
+                if constexpr (!K32) {  // more than 32 blocks of a type: step_pair64 is the only hot step this variant holds (registers)
+                    if (track_min != 0u)
+                        pair_loop(std::true_type{});
+                    else
+                        pair_loop(std::false_type{});
+                } else if (K8 && oct_mode) {
                     if (track_min != 0u)
                         oct_loop(std::true_type{});
                     else
@@ -1333,6 +1597,14 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 }
                 __syncthreads();
                 if (is_main) FSTAMP(10);  // (diagnostic builds: time spent waiting for the feeder)
+            }
+            if (!EL && is_main) {  // the window goes back to HBM: the other type's rows take its place
+                wfence();
+                for (uint32_t i = lane; i < k_own * eta_w; i += kWave) {
+                    const uint32_t row = i / eta_w, d = eta_lo + i % eta_w;
+                    if (d < D) eta_g[(own_base + row) * D + d] = eta_l[i];
+                }
+                wfence();
             }
         };
         run_phase(std::false_type{});
@@ -1378,14 +1650,18 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
         sc->last_rate = rate;
         sc->last_accepted = acc_l0;
         sc->last_sweeps = sweeps_done;
+        sc->stop_emin = emin_l0;  // (lane 0's copies are the values)
+        sc->stop_mark = mark_l0;
+        sc->stop_below1 = *below1_total;
+        sc->stopped = stopped ? 1u : 0u;
         // give the SIMD back: workgroups of a later round (more chains than the chip holds at once) claim afresh
         if (p.simd_claims != nullptr) atomicSub(&p.simd_claims[role[wave_in_wg]], 1u);
     }
 }
 
-size_t sweep_fast_lds_bytes(uint32_t ka, uint32_t kb, uint32_t maxdeg, bool eta_in_lds) {
+size_t sweep_fast_lds_bytes(uint32_t ka, uint32_t kb, uint32_t maxdeg, bool eta_in_lds, uint32_t eta_window) {
     const uint32_t K = ka + kb, D = maxdeg + 1, S = kb | 1u;
-    const size_t dwords = (size_t)ka * S + (eta_in_lds ? (size_t)K * D : 0) +
+    const size_t dwords = (size_t)ka * S + (eta_in_lds ? (size_t)K * D : (size_t)std::max(ka, kb) * eta_window) +
                           2 * (size_t)kWave * (kHistStride / 4) + 2 * (size_t)kHandWords * kWave + kWave + 4 + 10;
     // the step reads m[.][lane] for all 64 lanes whatever ka, kb are (idle lanes are masked after the read):
     // dword index <= 63 * S + 63 must be inside the allocation
@@ -1415,7 +1691,7 @@ static hipError_t launch_fast_variant(const SweepParams& p, size_t lds_bytes, hi
 
 hipError_t launch_sweep_fast(const SweepParams& p, size_t /*generic_lds_bytes*/, hipStream_t stream) {
     const bool ct = p.schedule == SCHED_CONSTANT;
-    const size_t lds_bytes = sweep_fast_lds_bytes(p.ka, p.kb, p.maxdeg, p.eta_in_lds != 0);
+    const size_t lds_bytes = sweep_fast_lds_bytes(p.ka, p.kb, p.maxdeg, p.eta_in_lds != 0, p.eta_w);
     hipError_t e;
     if (p.eta_in_lds)
         e = ct ? launch_fast_variant<true, true>(p, lds_bytes, stream) : launch_fast_variant<true, false>(p, lds_bytes, stream);

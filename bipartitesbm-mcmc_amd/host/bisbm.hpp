@@ -160,6 +160,7 @@ struct engine_options {  // what the reference does not have: chains, device, RN
     uint32_t n_chains = 1;
     uint32_t first_chain_id = 0;
     int device = 0;
+    std::vector<int> devices;  // more than one entry: the chains are spread over these devices behind one handle (bisbm_create_multi)
     int rng_mode = BISBM_RNG_MT19937_COMPAT;
     uint64_t seed = 0;      // std::mt19937 engine(seed) of mcmc_main.cc:242, or the Philox key
     uint64_t gen_seed = 0;  // the hidden blockmodel_t::gen (blockmodel.hh:17-18); the reference seeds it from random_device
@@ -174,9 +175,13 @@ public:
         size_t na = 0, nb = 0;
         for (auto t : types) (t == 0 ? na : nb) += 1;
         n_ = na + nb;
-        const int rc = bisbm_create(&h_, n_, na, nb, adj_list_ptr->rowptr.data(), adj_list_ptr->col.data(),
-                                    (uint32_t)KA, (uint32_t)KB, epsilon, opt.n_chains, opt.first_chain_id, opt.device,
-                                    opt.rng_mode, opt.seed, opt.gen_seed);
+        const int rc = opt.devices.size() > 1
+                           ? bisbm_create_multi(&h_, n_, na, nb, adj_list_ptr->rowptr.data(), adj_list_ptr->col.data(), (uint32_t)KA,
+                                                (uint32_t)KB, epsilon, opt.n_chains, opt.first_chain_id, opt.devices.data(),
+                                                (int)opt.devices.size(), opt.rng_mode, opt.seed, opt.gen_seed)
+                           : bisbm_create(&h_, n_, na, nb, adj_list_ptr->rowptr.data(), adj_list_ptr->col.data(), (uint32_t)KA,
+                                          (uint32_t)KB, epsilon, opt.n_chains, opt.first_chain_id,
+                                          opt.devices.empty() ? opt.device : opt.devices[0], opt.rng_mode, opt.seed, opt.gen_seed);
         if (rc != BISBM_OK) throw std::runtime_error(std::string("bisbm_create: ") + bisbm_last_error(nullptr));
         check(bisbm_set_memberships(h_, BISBM_ALL_CHAINS, memberships.data()));
     }
@@ -241,19 +246,12 @@ public:
     // (most frequent block, ties -> lowest index) in the reference's block numbering.
     void marginals_reset() { check(bisbm_marginals_reset(h_)); }
     void marginals_accumulate() { check(bisbm_marginals_accumulate(h_, nullptr)); }
-    uint_vec_t marginal_map_labels(size_t NA) {
-        const size_t kmax = std::max(KA_, KB_);
-        std::vector<uint32_t> counts(n_ * kmax);
-        check(bisbm_marginals_get(h_, counts.data()));
-        uint_vec_t out(n_);
-        for (size_t v = 0; v < n_; ++v) {
-            const uint32_t* row = &counts[v * kmax];
-            size_t best = 0;
-            for (size_t k = 1; k < kmax; ++k)
-                if (row[k] > row[best]) best = k;
-            out[v] = (unsigned)(best + (v >= NA ? KA_ : 0));
-        }
-        return out;
+    // the marginal estimate of README.md:49-53: every node's most frequent block, pooled over the handle's devices on the
+    // devices (bisbm_marginals_map)
+    uint_vec_t marginal_map_labels(size_t /*NA*/) {
+        std::vector<uint32_t> lab(n_);
+        check(bisbm_marginals_map(h_, lab.data()));
+        return uint_vec_t(lab.begin(), lab.end());
     }
     bisbm_handle handle() const { return h_; }
     uint32_t n_chains() const { return n_chains_; }

@@ -4,7 +4,7 @@
 // partition rules (:241-326), same stdout contract: the label vector through output_vec (trailing blank,
 // newline), "acceptance ratio" and summary() on clog (:483-485).  Boost.program_options is replaced by a
 // small parser with the same surface (long/short names, `--opt=value`, multitoken options).
-// Extra flags: --chains, --device, --rng {mt19937-compat,philox}, --gen_seed, --csr_cache, --reorder, --marginalize.
+// Extra flags: --chains, --device, --devices, --rng {mt19937-compat,philox}, --gen_seed, --csr_cache, --reorder, --marginalize.
 // The agglomerative drivers (:349-451) run through bisbm_agg_merge.  --merge starts at one block per node: while
 // KA + KB > 256 the library runs its wide mode (two-byte labels, generic kernel), up to about 14 000 blocks (bisbm_check_shape).
 // Negative diffs (agg_split) run through the same call (blockmodel.cc:110-117).
@@ -41,7 +41,7 @@ const option_spec kOptions[] = {
     {"epsilon", 'E', 1},        {"randomize", 'r', 0},     {"merge", 'g', 0},      {"nature", 'u', 0},
     {"seed", 'd', 1},           {"help", 'h', 0},
     // engine extras
-    {"chains", 0, 1},           {"device", 0, 1},          {"rng", 0, 1},          {"gen_seed", 0, 1},
+    {"chains", 0, 1},           {"device", 0, 1},          {"devices", 0, 1},          {"rng", 0, 1},          {"gen_seed", 0, 1},
     {"csr_cache", 0, 0},        {"reorder", 0, 0},         {"marginalize", 0, 0},
 };
 
@@ -154,7 +154,10 @@ void print_help(const char* argv0) {
                  "  --chains arg (=1)                     Independent chains; the labels of the chain with the lowest\n"
                  "                                        description length are printed.\n"
                  "  --device arg (=0)                     HIP device ordinal.\n"
-                 "  --rng arg (=mt19937-compat)           mt19937-compat (the reference's draw sequence) or philox.\n"
+                 "  --devices arg                         Comma-separated HIP device ordinals: the --chains are spread over them\n"
+                 "                                        (contiguous ranges, one handle; results do not depend on the split).\n"
+                 "  --rng arg                             mt19937-compat (the reference's draw sequence: the default when -d\n"
+                 "                                        is given) or philox (the production chain: the default otherwise).\n"
                  "  --gen_seed arg (=seed+1)              Seed of the reference's hidden second engine (blockmodel.hh:18).\n"
                  "  --reorder                             Renumber the nodes for memory locality before the run (ids without\n"
                  "                                        structure); labels are read and printed in the caller's numbering.\n"
@@ -400,7 +403,34 @@ int main(int argc, char const* argv[]) {
     engine_options opt;
     opt.n_chains = (uint32_t)std::strtoul(single("chains", "1").c_str(), nullptr, 10);
     opt.device = std::atoi(single("device", "0").c_str());
-    const std::string rng = single("rng", "mt19937-compat");
+    if (count("devices")) {
+        const std::string list = single("devices", "");
+        for (size_t pos = 0; pos <= list.size();) {
+            const size_t comma = std::min(list.find(',', pos), list.size());
+            const std::string item = list.substr(pos, comma - pos);
+            char* end = nullptr;
+            const long d = std::strtol(item.c_str(), &end, 10);
+            if (item.empty() || *end != '\0' || d < 0) {
+                std::cerr << "Invalid --devices. A comma-separated list of device ordinals, e.g. 0,1,2,3.\n";
+                return 1;
+            }
+            opt.devices.push_back((int)d);
+            pos = comma + 1;
+        }
+        if (opt.devices.size() > opt.n_chains) {
+            std::cerr << "--devices lists " << opt.devices.size() << " devices for --chains " << opt.n_chains << ": every device needs a chain.\n";
+            return 1;
+        }
+        opt.device = opt.devices[0];
+    }
+    // Without -d the reference seeds its engines from the clock and random_device (mcmc_main.cc:242, blockmodel.hh:17-18): there
+    // is no draw sequence to reproduce, so the production chain (Philox) runs.  With -d the default is the verification mode
+    // that reproduces the reference's own mt19937 sequence for that seed -- an order of magnitude slower per step.
+    const bool seed_given = count("seed") != 0;
+    const std::string rng = single("rng", seed_given ? "mt19937-compat" : "philox");
+    if (!count("rng") && seed_given)
+        std::clog << "rng: mt19937-compat (-d given: the reference's draw sequence for this seed; --rng philox runs the production chain, "
+                     "about ten times faster per step)\n";
     if (rng != "mt19937-compat" && rng != "philox") {
         std::cerr << "Invalid --rng. Options are mt19937-compat, philox.\n";
         return 1;
@@ -464,6 +494,8 @@ int main(int argc, char const* argv[]) {
                     engine_options one = opt;
                     one.n_chains = 1;
                     one.first_chain_id = opt.first_chain_id + c;
+                    if (!opt.devices.empty()) one.device = opt.devices[c % opt.devices.size()];  // (--devices: the runs take turns)
+                    one.devices.clear();
                     blockmodel_t blockmodel(memberships_init, types_init, NA + NB, NA, NB, epsilon, &adj_list, one);
                     blockmodel.init_bisbm();
                     metropolis_hasting algorithm;

@@ -78,6 +78,24 @@ int bisbm_create(bisbm_handle *out, uint64_t n, uint64_t na, uint64_t nb, const 
                  uint32_t first_chain_id, int device, int rng_mode, uint64_t seed,
                  uint64_t gen_seed);
 
+/* The same for chains spread over several devices of one node (no reference counterpart: the reference is one chain in one
+ * process; BASELINE north_star / SURVEY 8e: "chains shard trivially across the 8 GPUs of one node").  The n_chains chains are
+ * split into contiguous ranges, one per entry of devices[] (the first n_chains % n_devices ranges one chain longer); graph
+ * and tables are replicated per device; chain i keeps the global id first_chain_id + i, so every result equals what ONE
+ * device with all the chains gives.  Every other call works on the returned handle as on a single-device one (all-chain calls
+ * run the devices side by side, one host thread and one stream per device; there is no exchange during sweeps) except:
+ * bisbm_set_stream (refused) and bisbm_marginals_accumulate with a caller-owned buffer (refused: each device accumulates into
+ * its own; bisbm_marginals_map pools them on the devices, bisbm_marginals_get on the host).  A device may be listed more than
+ * once (rehearsal on a one-GPU box). */
+int bisbm_create_multi(bisbm_handle *out, uint64_t n, uint64_t na, uint64_t nb, const uint64_t *rowptr,
+                       const uint32_t *col, uint32_t ka, uint32_t kb, double epsilon, uint32_t n_chains,
+                       uint32_t first_chain_id, const int *devices, int n_devices, int rng_mode,
+                       uint64_t seed, uint64_t gen_seed);
+
+/* Devices behind a handle: their number, their ordinals and the first chain of each (arrays of *n_devices entries; any
+ * pointer may be NULL).  1 / {device} / {0} for a bisbm_create handle. */
+int bisbm_device_count(bisbm_handle h, int *n_devices, int *devices, uint32_t *first_chain);
+
 int bisbm_destroy(bisbm_handle h);
 
 /* Whether a handle of ka + kb blocks can be served, without creating one (no reference counterpart: blockmodel_t has no
@@ -140,6 +158,13 @@ int bisbm_get_last_counts(bisbm_handle h, uint64_t *accepted, uint64_t *sweeps);
 int bisbm_marginals_accumulate(bisbm_handle h, uint32_t *device_counts);
 int bisbm_marginals_reset(bisbm_handle h);
 int bisbm_marginals_get(bisbm_handle h, uint32_t *counts_out /* n*kmax, host */);
+
+/* The marginal estimate README.md:49-53 asks for: the most frequent block of every node over all samples of all chains (ties ->
+ * the lowest block), n labels in the reference's numbering, from the internal histogram.  Over several devices this is the
+ * exchange of SURVEY 8(e), on the devices: ncclReduceScatter of the per-device histograms by node range (RCCL over xGMI) ->
+ * argmax on the owner of the range -> ncclAllGather of the labels; peer copies + an add kernel where RCCL cannot serve (a
+ * device listed twice, librccl.so missing, BISBM_POOL=p2p). */
+int bisbm_marginals_map(bisbm_handle h, uint32_t *labels_out /* n, host */);
 
 /* blockmodel_t::agg_merge(engine, diff_a, diff_b, nm) (blockmodel.hh, blockmodel.cc:109-206; call sites
  * mcmc_main.cc:385,429,434,446): merge diff_a type-a and diff_b type-b blocks in every chain -- nm proposals per

@@ -12,7 +12,7 @@
  *                   (same proposal distribution, same dS, same accept rule, same bookkeeping)
  *                   driven by Philox4x32-10 counters, a Feistel visit order per sweep and type
  *                   (all type-a nodes, then all type-b nodes), an integer inverse-CDF draw, and a
- *                   fixed 64-leaf butterfly for the three FP64 sums (dS, accu0, accu1).
+ *                   fixed 64-leaf butterfly (levels 32,1,2,4,8,16) for the three FP64 sums (dS, accu0, accu1).
  *                   The GPU must match this mode bit-for-bit on integers.
  *
  * Paths cited below are relative to /root/reference/src.
@@ -904,10 +904,13 @@ double orc_compute_dS_vertex(orc_model *m, size_t v, size_t r, size_t s) {
     return entropy1 - entropy0;
 }
 
-/* fixed 64-leaf xor butterfly (levels 1,2,4,8,16,32): the summation tree the wave uses */
+/* fixed 64-leaf xor butterfly, levels 32, then 1,2,4,8,16: the summation tree the wave uses (level 32 first: a lane that
+ * holds two leaves adds its own pair before the cross-lane levels; with at most 32 leaves in use that level adds +0.0) */
 static double butterfly64(double *x) {
+    static const int levels[6] = {32, 1, 2, 4, 8, 16};
     double y[64];
-    for (int lvl = 1; lvl < 64; lvl <<= 1) {
+    for (int j = 0; j < 6; ++j) {
+        const int lvl = levels[j];
         for (int i = 0; i < 64; ++i) y[i] = x[i] + x[i ^ lvl];
         memcpy(x, y, sizeof(y));
     }

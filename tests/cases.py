@@ -47,6 +47,8 @@ CASES = [
     # the same for the four- and eight-steps-per-pass variants (both block counts <= 16, <= 8)
     ("k16_eta_in_hbm", 3000, 3000, 60000, 16, 13, 1.0, 1, 0),
     ("k8_eta_in_hbm", 3000, 3000, 60000, 8, 7, 1.0, 1, 0),
+    # ... and the one-step-per-pass variant (a block count above 32) with eta outside the LDS (a window of it inside)
+    ("k64_eta_in_hbm", 3000, 3000, 60000, 50, 64, 1.0, 1, 0),
     # epsilon = 0 (legal in the reference: -E 0): no uniform component in the proposal, denominators m_r[t] alone
     ("eps0", 300, 200, 3000, 5, 7, 0.0, 0, 4),
     ("eps0_direct", 20000, 20000, 100000, 2, 2, 0.0, 0, 0),

@@ -122,7 +122,10 @@ def test_matches_oracle(case, mode):
     # metropolis_hasting.cc:55-57 -- and corrupts its own state; the engine never does, see DESIGN.md "hazards")
     for sched, kw, dur, await_ in [("constant", [1.0], 6 * n, BIG), ("linear", [2.0, 1.5 / (3 * n)], 3 * n, BIG),
                                    ("abrupt_cool", [float(n)], 4 * n, BIG), ("exponential", [3.0, 0.999], 3 * n, 2 * n),
-                                   ("logarithmic", [1.0, 2.0], 2 * n, BIG)]:
+                                   ("logarithmic", [1.0, 2.0], 2 * n, BIG),
+                                   # T underflows to 0 inside the call; on the way 1 / T overflows for some fifty steps, where
+                                   # -1 / T * dS is +-inf or (r == s: dS = 0) NaN: accepted iff dS < 0 (metropolis_hasting.cc:54-59)
+                                   ("exponential", [1e-3, 0.5], 2 * n, BIG)]:
         ro = o.anneal(sched, kw, dur, await_)
         rg = mh.anneal(g, sched, kw, dur, await_)
         assert rg == ro, (sched, rg, ro)
@@ -131,6 +134,36 @@ def test_matches_oracle(case, mode):
         assert acc[0] == o.last_accepted and sw[0] == o.last_sweeps
         assert g.get_entropy()[0] == pytest.approx(o.get_entropy(), rel=1e-9, abs=1e-9)
     assert g.entropy()[0] == pytest.approx(o.entropy(), rel=1e-9)
+
+
+@pytest.mark.parametrize("window", ["3", "1", None])
+@pytest.mark.parametrize("name", ["k32_eta_in_hbm", "k64_eta_in_hbm", "k8_eta_in_hbm"])
+def test_eta_window_in_lds(name, window, monkeypatch):
+    """Where eta[K][max degree + 1] does not fit beside the rest of a chain's state in LDS (here: one hub of degree 600), the
+    production kernel keeps a window of it there -- the rows of the phase's own type, a run of consecutive degrees placed where
+    most nodes are -- and steps of nodes of other degrees take the general step with eta in HBM.  Whatever the window (the
+    library's choice, or three degrees / one degree wide: most steps outside), the chains equal the oracle's."""
+    if window is None:
+        monkeypatch.delenv("BISBM_ETA_WINDOW", raising=False)
+    else:
+        monkeypatch.setenv("BISBM_ETA_WINDOW", window)
+    _, na, nb, ne, ka, kb, eps, hubs, iso = cases.CASE[name]
+    rowptr, col = _random_graph(11, na, nb, ne, ka, kb, hubs, iso)
+    labels = O.contiguous_labels(na, nb, ka, kb)
+    n, chains, first = na + nb, 3, 11
+    g = gpu_model(rowptr, col, na, nb, ka, kb, eps, labels, n_chains=chains, rng="philox", seed=31, first_chain_id=first)
+    g.shuffle_bisbm()
+    mh = B.MetropolisHasting()
+    runs = [("constant", [1.0], 3 * n, BIG), ("exponential", [1.5, 0.9999], 6 * n, n), ("abrupt_cool", [1.5 * n], 3 * n, BIG)]
+    got = [mh.anneal(g, s_, kw, dur, aw).copy() for s_, kw, dur, aw in runs]
+    for c in range(chains):
+        o = O.OracleModel(rowptr, col, na, nb, ka, kb, eps, labels)
+        o.seed_philox(31, first + c)
+        o.shuffle_bisbm()
+        for (s_, kw, dur, aw), rates in zip(runs, got):
+            assert o.anneal(s_, kw, dur, aw) == rates[c], (s_, c)
+        assert_state_equal(g, o, c)
+        assert g.get_entropy()[c] == pytest.approx(o.get_entropy(), rel=1e-9)
 
 
 def test_hot_step_many_chains_philox():
@@ -156,14 +189,16 @@ def test_hot_step_many_chains_philox():
         assert cum[c] == pytest.approx(o.get_entropy(), rel=1e-9)
 
 
-def test_two_steps_per_pass_equals_the_serial_chain(monkeypatch):
-    """K = 32 + 32 at constant T: the production kernel evaluates steps q and q+1 in the two halves of the wave and
+@pytest.mark.parametrize("ka,kb", [(32, 32), (64, 64), (33, 57)])
+def test_two_steps_per_pass_equals_the_serial_chain(ka, kb, monkeypatch):
+    """(64 + 64 and 33 + 57 blocks: the variant for more than 32 blocks of a type, whose lanes hold two blocks each --
+    step_pair64 -- under the same checks, plus cooling schedules with the early stop armed.)
+    K = 32 + 32 at constant T: the production kernel evaluates steps q and q+1 in the two halves of the wave and
     commits both when step q provably left step q+1's inputs alone.  Many blocks make that the
     common case (with K = 2 + 2 nearly every pair clashes), so this is the test of the commit-both path: chains equal
     their oracle runs sweep by sweep -- from a randomised start (most steps move) and from the planted partition (most
     proposals are r == s) -- and equal the same kernel forced to one step per pass."""
     na = nb = 24_000
-    ka = kb = 32
     rowptr, col = _random_graph(5, na, nb, 480_000, ka, kb)
     n = na + nb
     planted = O.contiguous_labels(na, nb, ka, kb)
@@ -203,6 +238,15 @@ def test_two_steps_per_pass_equals_the_serial_chain(monkeypatch):
         assert np.allclose(g.get_entropy(), h.get_entropy(), rtol=0, atol=0)  # same sum, same order of additions
         for c, o in oracles:
             assert g.get_entropy()[c] == pytest.approx(o.get_entropy(), rel=1e-9)
+        if start == "planted":  # cooling schedules, the early stop armed, the greedy tail (T = 0), on the same chains
+            for sched, kw, dur, aw in [("exponential", [1.5, 0.99997], 4 * n, n // 2), ("abrupt_cool", [1.5 * n], 3 * n, BIG),
+                                       ("linear", [1.2, 1.0 / (2 * n)], 2 * n, BIG)]:
+                rates = mh.anneal(g, sched, kw, dur, aw)
+                for c, o in oracles:
+                    assert o.anneal(sched, kw, dur, aw) == rates[c], (sched, c)
+                    assert_state_equal(g, o, c)
+    if (ka, kb) != (32, 32):
+        return
     # a temperature other than 1 and a chunk that ends on an odd step (n_own not a multiple of 64)
     rowptr, col = _random_graph(6, 1003, 777, 30_000, 7, 5)
     lab = O.contiguous_labels(1003, 777, 7, 5)
@@ -375,6 +419,54 @@ def test_early_stop_fires_in_production_kernel():
             stopped_early += int(o.last_sweeps < dur // n)
         assert_state_equal(g, o, c)
     assert stopped_early >= 3 * chains  # (the stop did fire: every run but possibly one per chain ended before its duration)
+
+
+@pytest.mark.parametrize("case", ["direct_tier", "n_1000"])
+def test_cooling_calls_run_as_table_slices(case, monkeypatch):
+    """The production kernel holds no pow() / log(): the exponential and logarithmic schedules come from a host table
+    (glibc, the reference's own values), and a call longer than the table runs as several launches of whole sweeps, each with
+    its slice, the early-stop bookkeeping (metropolis_hasting.cc:75,85-98) carried over in the chain's scalars.  With the
+    table capped at a few sweeps (BISBM_T_TABLE_CAP) every chain must equal its oracle run -- rates, counts, state -- whether
+    the stop fires in the first slice, in a later one, or never, and equal the uncapped run."""
+    if case == "n_1000":
+        rowptr, col, na, nb = O.load_graph("n_1000")
+        ka, kb, eps = 4, 6, 1.0
+    else:
+        name, na, nb, ne, ka, kb, eps, hubs, iso = next(c for c in CASES if c[0] == "direct_tier")
+        rowptr, col = _random_graph(11, na, nb, ne, ka, kb, hubs, iso)
+    labels = O.contiguous_labels(na, nb, ka, kb)
+    n, chains, first = na + nb, 6, 5
+    runs = [("exponential", [2.0, 0.99995], 37 * n + 11, 1 << 60), ("exponential", [2.0, 0.9999], 40 * n, n // 2),
+            ("logarithmic", [1.0, 2.0], 23 * n, 1 << 60), ("logarithmic", [3.0, 2.0], 30 * n, 9 * n),
+            ("exponential", [1e-3, 0.5], 12 * n, 1 << 60),   # underflows to T = 0 inside the call: the greedy tail
+            ("exponential", [0.9, 0.99999], 31 * n, 0)]      # steps_await = 0 below T = 1: stops after the first sweep
+    out = {}
+    for cap in (str(3 * n + 17), str(1 << 22)):
+        monkeypatch.setenv("BISBM_T_TABLE_CAP", cap)
+        g = gpu_model(rowptr, col, na, nb, ka, kb, eps, labels, n_chains=chains, rng="philox", seed=777, first_chain_id=first)
+        g.shuffle_bisbm()
+        mh = B.MetropolisHasting()
+        got = []
+        for sched, kw, dur, await_ in runs:
+            rates = mh.anneal(g, sched, kw, dur, await_).copy()
+            acc, sw = g.last_counts()
+            got.append((rates, acc.copy(), sw.copy()))
+        out[cap] = (got, [g.get_memberships(c) for c in range(chains)], g.get_entropy().copy(), g)
+    a, b = out[str(3 * n + 17)], out[str(1 << 22)]
+    for (ra, aa, sa), (rb, ab, sb) in zip(a[0], b[0]):
+        assert (ra == rb).all() and (aa == ab).all() and (sa == sb).all()
+    assert all((x == y).all() for x, y in zip(a[1], b[1])) and (a[2] == b[2]).all()
+    early = 0
+    for c in range(chains):
+        o = O.OracleModel(rowptr, col, na, nb, ka, kb, eps, labels)
+        o.seed_philox(777, first + c)
+        o.shuffle_bisbm()
+        for (sched, kw, dur, await_), (rates, acc, sw) in zip(runs, a[0]):
+            assert o.anneal(sched, kw, dur, await_) == rates[c], (sched, kw, c)
+            assert (acc[c], sw[c]) == (o.last_accepted, o.last_sweeps), (sched, kw, c)
+            early += int(3 < o.last_sweeps < dur // n)
+        assert_state_equal(a[3], o, c)
+    assert early >= 1  # (a stop fired in a later slice)
 
 
 def test_config2_256_chains_philox():
