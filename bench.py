@@ -39,6 +39,20 @@ N_SIMDS = 256 * 4      # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md chip table)
 ISSUE_CYCLES = 4.0     # a wave64 VALU instruction occupies its SIMD for 4 cycles (same guide, cycle constants)
 
 
+def build_tag():
+    """What the numbers of a run belong to: a hash of the library's sources (the same on the build container and on the GPU
+    box; the .so itself is rebuilt per machine).  Profile summaries under profiles/ carry the tag of the build they were
+    measured on; bench.py quotes them as current only when it matches."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "bipartitesbm-mcmc_amd", "csrc")
+    for name in sorted(os.listdir(base)):
+        if name.endswith((".hip", ".hpp", ".cpp")):
+            with open(os.path.join(base, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:12]
+
+
 def b_alg_per_update(n, n_edges, label_bytes=1):
     """8 (two row offsets) + (4 + L) * mean degree (neighbour ids + labels) + 2 L."""
     return 8.0 + (4.0 + label_bytes) * (2.0 * n_edges / n) + 2.0 * label_bytes
@@ -61,6 +75,9 @@ def parse_args(argv=None):
                     help="run on this edge-list file instead of the synthetic graph (--na / --nb give the type sizes, --ka / --kb the "
                          "blocks of the contiguous initial partition); --edgelist n_1000 = the reference's shipped 1000-node data "
                          "set as BASELINE configs[1] runs it (Ka = 4, Kb = 6, 256 chains, 2000 sweeps per step)")
+    ap.add_argument("--steady-sweeps", type=int, default=0,
+                    help="after the timed region let the chains run on until they have done this many sweeps in all, then time "
+                         "three more: the steady-state figure, measured live (150 takes ~1.5 min at the default workload)")
     ap.add_argument("--sweeps-per-step", type=int, default=1, help="sweeps of every chain per timed step (small graphs: one launch should last milliseconds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -414,6 +431,26 @@ def main():
         assert lab.shape[0] == n
         del counts, send
 
+    # the same chains further along (a marginalize run lives there, not in the burn-in the protocol's sweeps see)
+    steady_live = None
+    sweeps_so_far = (len(spin_ms) + args.warmup + args.steps) * args.sweeps_per_step
+    if args.steady_sweeps > sweeps_so_far:
+        left = args.steady_sweeps - sweeps_so_far
+        while left > 0:  # (long calls at constant T run as several launches inside the library anyway)
+            now = min(left, 25)
+            mh.anneal(model, pkg.constant_schedule, [1.0], n * now, 1 << 60)
+            left -= now
+        sync()
+        sms, supd = 0.0, 0
+        for _ in range(3):
+            sweep()
+            ms, upd = model.last_sweep_timing()
+            sms += ms
+            supd += upd
+        steady_live = {"updates_per_s_per_gpu": supd / (sms / 1e3), "avg_launch_ms": sms / 3, "sweeps_before": args.steady_sweeps,
+                       "accepted_fraction": float(model.last_counts()[0].sum()) / (n * args.sweeps_per_step * shard.n_local),
+                       "what": "the same chains after %d sweeps in all, 3 sweeps timed (kernel time), measured in this run" % args.steady_sweeps}
+
     # the same workload from an equilibrated start: every chain on the planted partition (the posterior mode of this
     # generator), a few sweeps to settle, then timed -- the regime a long marginalize run lives in
     equil = None
@@ -444,25 +481,42 @@ def main():
         # HBM bytes per launch and instructions per update from the PMC passes committed under profiles/ (rocprofv3
         # --pmc, separate runs of this same command); only quoted for the workload they were measured on
         traffic, traffic_src, issue, steady = None, None, None, None
+        tag = build_tag()
+
+        def tagged(name):  # a profile summary and whether it was measured on THIS build
+            j = profile_json(name)
+            if j is None:
+                return None, False
+            return j, j.get("build") == tag
+
         if default_cfg:
-            tj = profile_json("r02_traffic.json") or profile_json("r01_traffic.json")
+            tj, cur = tagged("r03_traffic.json")
             if tj:
                 traffic = tj["bytes_per_update"] * per_launch_updates
-                traffic_src = "%s (FETCH_SIZE+WRITE_SIZE, %.0f B per update%s)" % (
-                    tj.get("_file", "profiles/*_traffic.json"), tj["bytes_per_update"],
-                    ", calibration: " + tj["calibration"] if "calibration" in tj else "")
-            ij = profile_json("r02_issue.json")
+                traffic_src = "%s (FETCH_SIZE+WRITE_SIZE, %.0f B per update%s; measured on build %s%s)" % (
+                    tj.get("_file", "profiles/r03_traffic.json"), tj["bytes_per_update"],
+                    ", calibration: " + tj["calibration"] if "calibration" in tj else "", tj.get("build"),
+                    "" if cur else " -- NOT this build (%s): re-take with tools/profile.sh" % tag)
+            ij, cur = tagged("r03_issue.json")
             if ij:
-                # Instruction-issue ceiling: a lone stepping wave per SIMD issues one instruction per >= 4 cycles, so
-                # updates/s <= SIMDs x clock / (instructions per update x 4 cycles)
-                ipu, clk = ij["instructions_per_update"], ij["clock_ghz"]
+                # Instruction-issue ceilings.  All kinds: a lone stepping wave per SIMD issues one instruction of any kind per
+                # >= 4 cycles, so updates/s <= SIMDs x clock / (instructions per update x 4).  VALU only: what the vector
+                # unit alone allows if scalar / LDS / memory instructions of other waves filled every other slot.
+                ipu, clk, vpu = ij["instructions_per_update"], ij["clock_ghz"], ij["valu_per_update"]
                 peak = N_SIMDS * clk * 1e9 / (ipu * ISSUE_CYCLES)
+                peak_valu = N_SIMDS * clk * 1e9 / (vpu * ISSUE_CYCLES)
                 ups = per_launch_updates / avg_kernel_s
-                issue = {"instructions_per_update": ipu, "valu_per_update": ij.get("valu_per_update"),
+                issue = {"instructions_per_update": ipu, "valu_per_update": vpu, "salu_per_update": ij.get("salu_per_update"),
                          "cycles_per_instruction": ISSUE_CYCLES, "simds": N_SIMDS, "clock_ghz": clk,
                          "peak_updates_per_s": peak, "achieved_updates_per_s": ups, "frac": ups / peak,
-                         "source": ij.get("_file", "profiles/r02_issue.json")}
-            steady = profile_json("r02_steady_state.json")
+                         "valu_only_peak_updates_per_s": peak_valu, "valu_only_frac": ups / peak_valu,
+                         "source": ij.get("_file", "profiles/r03_issue.json"), "measured_on_build": ij.get("build"),
+                         "current_build": cur}
+            steady, cur = tagged("r03_steady_state.json")
+            if steady:
+                steady = dict(steady, current_build=cur)
+        if steady_live is not None:
+            steady = dict(steady or {}, live=steady_live)
         roofline = {
             "bound": "hbm", "kernel": "sweep_fast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -501,6 +555,7 @@ def main():
                 "parallelism": "chains sharded, no collective in the sweep path",
                 "collective_backend": (backend if world > 1 else None), "collective_backend_note": backend_note,
             },
+            "build": tag,
             "roofline": roofline,
             "equilibrated_start": equil,
             "steady_state": steady,

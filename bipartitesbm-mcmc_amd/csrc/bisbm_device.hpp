@@ -79,20 +79,45 @@ __device__ __forceinline__ double butterfly_sum(double x) {
     return readlane(x, 63u);
 }
 
-// Two 64-leaf butterfly sums for the price of one: the swap that folds a (lanes 0..31 + lanes 32..63) leaves the lower half for
-// a's fold and the upper half for b's, and the five row levels run once for both.  Same tree, same bits as butterfly_sum(a),
-// butterfly_sum(b).
-__device__ __forceinline__ void butterfly_pair64(double a, double b, double& sum_a, double& sum_b) {
-    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
-    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
-    double x = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);  // [a.lo, b.lo] + [a.hi, b.hi]
+// The two Hastings sums (accu0, accu1) use the tree with level 16 SECOND -- levels 32, 16, then 1,2,4,8 -- so that a pass which
+// holds one step per 32-lane half can fold BOTH sums with one v_permlane16_swap pair (rows 0 / 2 keep accu0's leaves l + l ^ 16,
+// rows 1 / 3 accu1's) and run the four row levels once for both (butterfly_accu_rows32): 17 instructions instead of 30.  The
+// dS sum keeps levels 32, 1,2,4,8,16 (butterfly_sum and its shortened forms).  The CPU checker restates both trees.
+__device__ __forceinline__ double butterfly_fold16(double x) {  // every lane: leaf l + leaf l ^ 16 (rows 0 <-> 1, 2 <-> 3)
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(x), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(x), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);  // [r0, r0, r2, r2] + [r1, r1, r3, r3]
+}
+__device__ __forceinline__ double butterfly_rows_1248(double x) {
     x = x + dpp_f64<kDppXor1>(x);
     x = x + dpp_f64<kDppXor2>(x);
     x = x + dpp_f64<kDppHalfMirror>(x);
     x = x + dpp_f64<kDppMirror>(x);
-    x = x + dpp_f64<kDppBcast15, 0xA>(x);
+    return x;
+}
+// one Hastings sum over 64 leaves (the generic kernel)
+__device__ __forceinline__ double butterfly_sum_accu(double x) {
+    return readlane(butterfly_rows_1248(butterfly_fold16(butterfly_fold32(x))), 63u);
+}
+// accu0, accu1 over 64 leaves each (general step of the production kernel with more than 32 blocks): the level-32 swap leaves
+// the lower half for a's fold and the upper half for b's
+__device__ __forceinline__ void butterfly_pair64(double a, double b, double& sum_a, double& sum_b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    double x = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);  // [a.lo, b.lo] + [a.hi, b.hi]
+    x = butterfly_rows_1248(butterfly_fold16(x));
     sum_a = readlane(x, 31u);
     sum_b = readlane(x, 63u);
+}
+// accu0, accu1 of TWO steps at once, one step per 32-lane half (leaves = the half's lanes; leaves 32..63 of the tree are
+// +0.0).  Afterwards every lane of rows 1 and 3 holds both sums of its half.
+__device__ __forceinline__ void butterfly_accu_rows32(double a0, double a1, double& accu0, double& accu1) {
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a0), __double2loint(a1), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a0), __double2hiint(a1), false, false);
+    // [a0.r0, a1.r0, a0.r2, a1.r2] + [a0.r1, a1.r1, a0.r3, a1.r3]: level 16 of both sums
+    const double x = butterfly_rows_1248(__hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]));
+    accu1 = x;                                // rows 1, 3
+    accu0 = dpp_f64<kDppBcast15, 0xA>(x);     // rows 0, 2 -> rows 1, 3
 }
 
 // The tree of rounds 1 and 2 (levels 1,2,4,8,16,32 in that order), kept for entropy()'s block-state sum, whose recorded
@@ -115,11 +140,7 @@ __device__ __forceinline__ void butterfly_pair32(double a, double b, double& sum
     const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
     const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
     double x = __hiloint2double(hi[0], lo[0]);  // lanes 0..31: a, lanes 32..63: b's lanes 0..31
-    x = x + dpp_f64<kDppXor1>(x);
-    x = x + dpp_f64<kDppXor2>(x);
-    x = x + dpp_f64<kDppHalfMirror>(x);
-    x = x + dpp_f64<kDppMirror>(x);
-    x = x + dpp_f64<kDppBcast15, 0xA>(x);
+    x = butterfly_rows_1248(butterfly_fold16(x));  // (the Hastings sums' tree: level 16 before the row levels)
     sum_a = readlane(x, 31u);
     sum_b = readlane(x, 63u);
 }
@@ -597,6 +618,11 @@ __device__ __forceinline__ double log_q_closed(double kd, double sq, double r, d
     const double a = __builtin_fma(u * u, 0.25, kd + 0.5);
     const double t2 = c.c2c0 * sq;
     const double corr = __builtin_fma(x, a, -__builtin_fma(eps, t2, eps));
+#ifndef BISBM_EXP_NO_LOGN_LATE
+    // (scheduling only: log n comes out of a table gather that is still in flight when the evaluation starts -- tying it to
+    // `corr` here keeps the compiler from placing its first use, and with it the wait for the gather, at the top)
+    __asm__ volatile("" : "+v"(logn) : "v"(corr));
+#endif
     return ((c.lfc - logn) + t2) + corr;
 }
 
@@ -648,6 +674,9 @@ __device__ __forceinline__ double log_q_closed2(double kd, double sq, double r, 
     // log v - log u = log(pi/sqrt 6) + log(1 - delta);   -log1p(-y)/2 = y (1 + y/2) / 2
     const double lf = (c.lfc - delta * __builtin_fma(0.5, delta, 1.0)) + 0.5 * y * __builtin_fma(0.5, y, 1.0);
     const double g = __builtin_fma(c.c2c0, 1.0 - delta, u * x * __builtin_fma(0.5, x, 1.0));  // 2 v / u - u log1p(-x)
+#ifndef BISBM_EXP_NO_LOGN_LATE
+    __asm__ volatile("" : "+v"(logn) : "v"(g));  // (scheduling only, see log_q_closed)
+#endif
     return (lf - logn) + sq * g;
 }
 

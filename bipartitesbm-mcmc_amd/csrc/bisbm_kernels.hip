@@ -374,8 +374,8 @@ __device__ __forceinline__ bool mh_step(const SweepParams& p, const Tables& tab,
             if (lane < 8) d = d + (neg_tail ? -tail_lg : tail_lg);
             if (lane < 4) d = d + (lane < 2 ? -lq : lq);
             dS = butterfly_sum(d);
-            phx_accu0 = (deg == 0) ? 1. : butterfly_sum(accu0);
-            phx_accu1 = (deg == 0) ? 1. : butterfly_sum(accu1);
+            phx_accu0 = (deg == 0) ? 1. : butterfly_sum_accu(accu0);
+            phx_accu1 = (deg == 0) ? 1. : butterfly_sum_accu(accu1);
         } else {
         // (4) scalar tail in the reference's statement order
         entropy0 -= -readlane(tail_lg, 0);  // :164-168

@@ -860,17 +860,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         }
                         return 1u + pairable;
                     }
-                    // Would step q, if it moves its node, touch what step q + 1 read?  (block sets as bit masks)
-                    const uint32_t setA = (1u << r_locA) | (1u << s_locA), setB = (1u << r_locB) | (1u << s_locB);
-                    const uint32_t lo = min(r_locA, s_locA), hi = max(r_locA, s_locA);
-                    const uint32_t between = ((1u << hi) - 1u) & ~((2u << lo) - 1u);  // blocks strictly between r and s
-                    const uint32_t kAtB = readlane(kk, t_locB);                        // (lanes 0..31 hold k_q[.])
-                    const uint32_t clash = sflag(setA & setB) | (((between >> s_locB) & 1u) & sflag(kAtB));
-                    // what the verdicts will be combined with, in one word (the scalar file is full): bit 0 step q can
-                    // move, bit 1 step q is an accepted r == s, bits 2, 3 the same for step q + 1, bit 4 the clash
-                    const uint32_t flags = (liveA & (selfA ^ 1u)) | ((liveA & selfA & warmA) << 1) | ((liveB & (selfB ^ 1u)) << 2) |
-                                           ((liveB & selfB & warmB) << 3) | (clash << 4);
-
                     const uint32_t s_loc = (uint32_t)((int)s_locA + __mul24((int)half, (int)s_locB - (int)s_locA));
                     const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
                     const uint32_t a_st = mq_at(s_loc, lb);
@@ -889,10 +878,34 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double L2 = tab_at(tab.lg, (uint32_t)(m_st + 1));
                     const double L4 = tab_at(tab.lg, (uint32_t)(m_st + 1) + kk);
                     FSTAMP_STEP(3);
+                    // (the verdict logic's inputs are worked out here, while the table gathers are in flight -- after the gathers have
+                    // been issued, not in front of them -- and pinned so that the compiler does not sink them behind the verdicts)
+                    // Would step q, if it moves its node, touch what step q + 1 read?  (block sets as bit masks)
+                    const uint32_t setA = (1u << r_locA) | (1u << s_locA), setB = (1u << r_locB) | (1u << s_locB);
+                    const uint32_t lo = min(r_locA, s_locA), hi = max(r_locA, s_locA);
+                    const uint32_t between = ((1u << hi) - 1u) & ~((2u << lo) - 1u);  // blocks strictly between r and s
+                    const uint32_t kAtB = readlane(kk, t_locB);                        // (lanes 0..31 hold k_q[.])
+                    const uint32_t clash = sflag(setA & setB) | (((between >> s_locB) & 1u) & sflag(kAtB));
+                    // what the verdicts will be combined with, in one word (the scalar file is full): bit 0 step q can
+                    // move, bit 1 step q is an accepted r == s, bits 2, 3 the same for step q + 1, bit 4 the clash
+                    const uint32_t flags = (liveA & (selfA ^ 1u)) | ((liveA & selfA & warmA) << 1) | ((liveB & (selfB ^ 1u)) << 2) |
+                                           ((liveB & selfB & warmB) << 3) | (clash << 4);
+
+                    uint32_t flags_pin = flags;
+                    __asm__ volatile("" : "+s"(flags_pin));
+                    (void)flags_pin;
+                    // ... and so is everything of apply_mcmc_moves that does not depend on the verdicts: the values to be written
+                    // and the per-lane changes of m_r / n_r, to be masked by the movers afterwards
+                    int dlA = (int)min(lb ^ r_locA, 1u) - (int)min(lb ^ s_locA, 1u);  // +1 on lane s, -1 on lane r
+                    int dlB = (int)min(lb ^ r_locB, 1u) - (int)min(lb ^ s_locB, 1u);
+                    int dmA = __mul24((int)degA, dlA), dmB = __mul24((int)degB, dlB);
+                    int wr_rt = m_rt_raw - k, wr_st = m_st_raw + k, wr_eta = ee + ((int)(lb & 1u) * 2 - 1);
+                    __asm__ volatile("" : "+v"(dlA), "+v"(dlB), "+v"(dmA), "+v"(dmB), "+v"(wr_rt), "+v"(wr_st), "+v"(wr_eta));
+
                     const double a0 = k * (m_st + eps) * inv_blk;
                     const double a1 = k * (m_rt - k + eps) * inv_blk;
-                    const double accu0 = butterfly_rows32(a0);  // lanes 16..31: step q, lanes 48..63: step q + 1
-                    const double accu1 = butterfly_rows32(a1);
+                    double accu0, accu1;  // lanes 16..31: step q, lanes 48..63: step q + 1
+                    butterfly_accu_rows32(a0, a1, accu0, accu1);
                     FSTAMP_STEP(4);
                     double lq;
                     {
@@ -963,16 +976,14 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         const unsigned long long movers = ((unsigned long long)mB << 32) | mA;
                         wfence();
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & lanes_koth)) {  // k == 0: rewrites the same values
-                            mq[a_rt] = m_rt_raw - k;
-                            mq[a_st] = m_st_raw + k;
+                            mq[a_rt] = wr_rt;
+                            mq[a_st] = wr_st;
                         }
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000003000000030ull))  // lanes 4, 5: eta_r - 1, eta_s + 1
-                            eta_l[e_idx] = (uint32_t)(ee + ((int)(lb & 1u) * 2 - 1));
+                            eta_l[e_idx] = (uint32_t)wr_eta;
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000000100000001ull)) labels[v] = (uint8_t)(own_base + s_loc);
-                        const int dlA = (int)min(lb ^ r_locA, 1u) - (int)min(lb ^ s_locA, 1u);  // +1 on lane s, -1 on lane r
-                        const int dlB = (int)min(lb ^ r_locB, 1u) - (int)min(lb ^ s_locB, 1u);
-                        mr_own += __mul24((int)(degA & mA), dlA) + __mul24((int)(degB & mB), dlB);
-                        nr_own += __mul24((int)chA, dlA) + __mul24((int)chB, dlB);
+                        mr_own += (dmA & (int)mA) + (dmB & (int)mB);
+                        nr_own += (dlA & (int)mA) + (dlB & (int)mB);
                         // :500, in step order; a step that does not move adds +0.0 (x + 0.0 is x: the running sum is never -0.0)
                         cum_l0 += __hiloint2double(dS_A_hi & (int)mA, dS_A_lo & (int)mA);
                         if constexpr (TM)
@@ -1043,19 +1054,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         }
                         return 1u + pairable;
                     }
-                    // would step q, if it moves its node, touch what step q + 1 read?  (step_pair's rule on 64-bit block sets)
-                    const unsigned long long setA = (1ull << r_locA) | (1ull << s_locA), setB = (1ull << r_locB) | (1ull << s_locB);
-                    const uint32_t lo = min(r_locA, s_locA), hi = max(r_locA, s_locA);
-                    const unsigned long long between = ((1ull << hi) - 1ull) & ~((2ull << lo) - 1ull);
-                    // (lanes 0..31 hold step q's k: block t_locB is the lower or the upper leaf of lane t_locB & 31; selections
-                    // stay arithmetic on scalar words, see sflag)
-                    const uint32_t kA0 = readlane(kk0, t_locB & 31u), kA1 = readlane(kk1, t_locB & 31u);
-                    const uint32_t kAtB = kA0 + (t_locB >> 5) * (kA1 - kA0);
-                    const unsigned long long common = setA & setB;
-                    const uint32_t clash = sflag((uint32_t)common | (uint32_t)(common >> 32)) | ((uint32_t)((between >> s_locB) & 1ull) & sflag(kAtB));
-                    const uint32_t flags = (liveA & (selfA ^ 1u)) | ((liveA & selfA & warmA) << 1) | ((liveB & (selfB ^ 1u)) << 2) |
-                                           ((liveB & selfB & warmB) << 3) | (clash << 4);
-
                     const uint32_t s_loc = (uint32_t)((int)s_locA + __mul24((int)half, (int)s_locB - (int)s_locA));
                     const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
                     const uint32_t a_st0 = mq_at(s_loc, lh), a_st1 = mq_at(s_loc, lh + 32u);
@@ -1073,11 +1071,32 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double logn = tab_at(tab.logtab, (uint32_t)qn);
                     const double L2_0 = tab_at(tab.lg, (uint32_t)(m_st0 + 1)), L4_0 = tab_at(tab.lg, (uint32_t)(m_st0 + 1) + kk0);
                     const double L2_1 = tab_at(tab.lg, (uint32_t)(m_st1 + 1)), L4_1 = tab_at(tab.lg, (uint32_t)(m_st1 + 1) + kk1);
+                    // (worked out while the gathers are in flight and pinned there, see step_pair: the verdict logic's inputs ...)
+                    // would step q, if it moves its node, touch what step q + 1 read?  (step_pair's rule on 64-bit block sets)
+                    const unsigned long long setA = (1ull << r_locA) | (1ull << s_locA), setB = (1ull << r_locB) | (1ull << s_locB);
+                    const uint32_t lo = min(r_locA, s_locA), hi = max(r_locA, s_locA);
+                    const unsigned long long between = ((1ull << hi) - 1ull) & ~((2ull << lo) - 1ull);
+                    // (lanes 0..31 hold step q's k: block t_locB is the lower or the upper leaf of lane t_locB & 31; selections
+                    // stay arithmetic on scalar words, see sflag)
+                    const uint32_t kA0 = readlane(kk0, t_locB & 31u), kA1 = readlane(kk1, t_locB & 31u);
+                    const uint32_t kAtB = kA0 + (t_locB >> 5) * (kA1 - kA0);
+                    const unsigned long long common = setA & setB;
+                    const uint32_t clash = sflag((uint32_t)common | (uint32_t)(common >> 32)) | ((uint32_t)((between >> s_locB) & 1ull) & sflag(kAtB));
+                    const uint32_t flags = (liveA & (selfA ^ 1u)) | ((liveA & selfA & warmA) << 1) | ((liveB & (selfB ^ 1u)) << 2) |
+                                           ((liveB & selfB & warmB) << 3) | (clash << 4);
+                    uint32_t flags_pin = flags;
+                    __asm__ volatile("" : "+s"(flags_pin));
+                    (void)flags_pin;
+                    // (... and what apply_mcmc_moves will write, to be masked by the movers)
+                    int dlA = (int)min(lane ^ r_locA, 1u) - (int)min(lane ^ s_locA, 1u);  // +1 on lane s, -1 on lane r (lane <-> block)
+                    int dlB = (int)min(lane ^ r_locB, 1u) - (int)min(lane ^ s_locB, 1u);
+                    int dmA = __mul24((int)degA, dlA), dmB = __mul24((int)degB, dlB);
+                    __asm__ volatile("" : "+v"(dlA), "+v"(dlB), "+v"(dmA), "+v"(dmB));
                     // the lane's two leaves of each sum, added first (level 32)
                     const double a0 = k0 * (m_st0 + eps) * inv_lo + k1 * (m_st1 + eps) * inv_hi;
                     const double a1 = k0 * (m_rt0 - k0 + eps) * inv_lo + k1 * (m_rt1 - k1 + eps) * inv_hi;
-                    const double accu0 = butterfly_rows32(a0);  // lanes 16..31: step q, lanes 48..63: step q + 1
-                    const double accu1 = butterfly_rows32(a1);
+                    double accu0, accu1;  // lanes 16..31: step q, lanes 48..63: step q + 1
+                    butterfly_accu_rows32(a0, a1, accu0, accu1);
                     double lq;
                     {
                         const int qk2 = qk < qn ? qk : qn;
@@ -1145,10 +1164,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000003000000030ull))  // lanes 4, 5: eta_r - 1, eta_s + 1
                             eta_l[e_idx] = (uint32_t)(ee + ((int)(lh & 1u) * 2 - 1));
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000000100000001ull)) labels[v] = (uint8_t)(own_base + s_loc);
-                        const int dlA = (int)min(lane ^ r_locA, 1u) - (int)min(lane ^ s_locA, 1u);  // +1 on lane s, -1 on lane r (lane <-> block)
-                        const int dlB = (int)min(lane ^ r_locB, 1u) - (int)min(lane ^ s_locB, 1u);
-                        mr_own += __mul24((int)(degA & mA), dlA) + __mul24((int)(degB & mB), dlB);
-                        nr_own += __mul24((int)chA, dlA) + __mul24((int)chB, dlB);
+                        mr_own += (dmA & (int)mA) + (dmB & (int)mB);
+                        nr_own += (dlA & (int)mA) + (dlB & (int)mB);
                         cum_l0 += __hiloint2double(dS_A_hi & (int)mA, dS_A_lo & (int)mA);
                         if constexpr (TM)
                             if (okA) new_minimum(q);

@@ -904,10 +904,10 @@ double orc_compute_dS_vertex(orc_model *m, size_t v, size_t r, size_t s) {
     return entropy1 - entropy0;
 }
 
-/* fixed 64-leaf xor butterfly, levels 32, then 1,2,4,8,16: the summation tree the wave uses (level 32 first: a lane that
- * holds two leaves adds its own pair before the cross-lane levels; with at most 32 leaves in use that level adds +0.0) */
-static double butterfly64(double *x) {
-    static const int levels[6] = {32, 1, 2, 4, 8, 16};
+/* fixed 64-leaf xor butterflies: the summation trees the wave uses.  dS: levels 32, then 1,2,4,8,16 (level 32 first: a lane that
+ * holds two leaves adds its own pair before the cross-lane levels); the two Hastings sums: levels 32, 16, then 1,2,4,8 (level 16
+ * second: one row swap folds both sums of a step at once).  With fewer leaves in use the levels that only add +0.0 drop out. */
+static double butterfly64_levels(double *x, const int *levels) {
     double y[64];
     for (int j = 0; j < 6; ++j) {
         const int lvl = levels[j];
@@ -915,6 +915,14 @@ static double butterfly64(double *x) {
         memcpy(x, y, sizeof(y));
     }
     return x[0];
+}
+static double butterfly64(double *x) {
+    static const int levels[6] = {32, 1, 2, 4, 8, 16};
+    return butterfly64_levels(x, levels);
+}
+static double butterfly64_accu(double *x) {
+    static const int levels[6] = {32, 16, 1, 2, 4, 8};
+    return butterfly64_levels(x, levels);
 }
 
 /* metropolis_hasting.cc:103-192.  Requires m->kv == k_[v].  Returns dS and sets m->accu_r. */
@@ -983,8 +991,8 @@ static double transition_ratio(orc_model *m, size_t v, size_t r, size_t s) {
         d[1] = d[1] + -orc_log_q_philox(m0s, n_r_s);
         d[2] = d[2] + orc_log_q_philox(m1r, n_r_r - 1);
         d[3] = d[3] + orc_log_q_philox(m1s, n_r_s + 1);
-        m->phx_accu0 = deg == 0 ? 1. : butterfly64(a0);
-        m->phx_accu1 = deg == 0 ? 1. : butterfly64(a1);
+        m->phx_accu0 = deg == 0 ? 1. : butterfly64_accu(a0);
+        m->phx_accu1 = deg == 0 ? 1. : butterfly64_accu(a1);
         m->accu_r = m->phx_accu1 / m->phx_accu0;
         return butterfly64(d);
     }

@@ -7,6 +7,9 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import build_tag  # noqa: E402  (the summaries carry the tag of the build they were measured on)
+BUILD = os.environ.get("BISBM_BUILD_TAG") or build_tag()
 P = os.path.join(ROOT, "profiles")
 rnd, tag = sys.argv[1], sys.argv[2]
 pre = "%s_%s" % (rnd, tag)
@@ -17,10 +20,11 @@ fetch, write = c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024
 ids_alg = 8 + 4 * 20.0
 traffic = {
     "_file": "profiles/%s_traffic.json" % rnd,
+    "build": BUILD,
     "_what": "HBM traffic of sweep_fast_kernel<true,true,true> (two steps per pass) at BASELINE configs[2], 1024 chains, one "
              "sweep = 1.024e9 node updates per launch; rocprofv3 --pmc in separate passes (3 launches each: 2 spin-up + 1 "
              "timed, counters divided by 3); counter unit KB",
-    "source": ["profiles/%s_pmc_counters.csv" % pre, "profiles/%s_fetch_calibration.json" % rnd],
+    "source": ["profiles/%s_pmc_counters.csv" % pre, "profiles/r02_fetch_calibration.json"],
     "updates_per_launch": upd,
     "fetch_bytes_per_update_as_counted": fetch / upd, "write_bytes_per_update": write / upd,
     "calibration": "known-bytes runs (tools/probe/fetch_calib.hip, 2 GiB touched once): 16-B and 4-B coalesced streams and "
@@ -41,6 +45,7 @@ avg_s = float(ks["AverageNs"]) / 1e9
 ipu = sum(c[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_BRANCH", "SQ_INSTS_SMEM")) / upd
 issue = {
     "_file": "profiles/%s_issue.json" % rnd,
+    "build": BUILD,
     "_what": "instructions per node update of sweep_fast_kernel<true,true,true>, both waves of a chain (stepping + feeder), "
              "rocprofv3 --pmc SQ_INSTS_* (profiles/%s_pmc_counters.csv), and the clock from GRBM_GUI_ACTIVE / 8 XCDs / kernel time" % pre,
     "instructions_per_update": ipu, "valu_per_update": c["SQ_INSTS_VALU"] / upd, "salu_per_update": c["SQ_INSTS_SALU"] / upd,
@@ -49,6 +54,7 @@ issue = {
     "clock_ghz": c["GRBM_GUI_ACTIVE"] / 8 / avg_s / 1e9, "kernel_avg_s_under_rocprof": avg_s,
     "wait_any_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], "active_inst_frac": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"],
     "round1": {"instructions_per_update": 241, "valu": 177, "salu": 36, "lds": 10.3, "vmem": 7.5, "branch": 10},
+    "round2": {"instructions_per_update": 214.4, "valu": 125.8, "salu": 69.9, "lds": 8.7, "vmem": 4.7, "branch": 5.2},
 }
 json.dump(issue, open(os.path.join(P, rnd + "_issue.json"), "w"), indent=1)
 
@@ -58,7 +64,7 @@ def bench(name):
     return json.load(open(path)) if os.path.exists(path) else None
 
 
-steady = {"_file": "profiles/%s_steady_state.json" % rnd,
+steady = {"_file": "profiles/%s_steady_state.json" % rnd, "build": BUILD,
           "_what": "the bench workload further along and with scrambled ids, one MI355X, kernel %s: --spinup 150 (156 sweeps before "
                    "the warm-up); --shuffle-ids without and with the ingest-time renumbering" % tag}
 for key, name, what in (("after_150_sweeps", pre + "_bench_after_150_sweeps.json", "same command with --spinup 150"),
