@@ -160,6 +160,12 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
     __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
     uint32_t* const role = lds32 + o_flag + 1;  // [0], [1]: the waves' SIMD slots; [2]: the wave that steps
+    // New labels of the chunk's nodes, one byte per step (0xff: the node stayed): a step that moves its node writes here, and
+    // the chunk's label stores to HBM go out together when its steps are done.  A node is visited once per sweep and the
+    // labels of its own type are read by nobody during the phase, so the delay changes nothing -- but a store issued inside
+    // the pass is still in flight at the top of the next one, where the compiler's wait for "all vector memory operations"
+    // (it cannot prove that no load into a reused register is pending) then waits for it.
+    uint8_t* const new_lab = (uint8_t*)(lds32 + o_flag + 8);
     if (lane == 0) role[wave_in_wg] = ((xcc_id & 0xfu) << 10) | ((hw_id >> 6) & 0x3fcu) | ((hw_id >> 4) & 3u);
     __syncthreads();
     if (wave_in_wg == 0 && lane == 0) {
@@ -237,7 +243,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     BISBM_PIN(c_tol, 1e-5);                        // accept filter margin
     LogQConsts lqc = log_q_consts();  // log_q closed form
     __asm__ volatile("" : "+v"(lqc.nc0l2e), "+v"(lqc.c1c0), "+v"(lqc.c1), "+v"(lqc.c2c0), "+v"(lqc.lfc));
-    BISBM_PIN(c_576, 576.0);                       // 24^2: tier test k^2 > 576 n
+    double c_576 = 576.0;                          // 24^2: tier test k^2 > 576 n
+    if (K32 || CT) __asm__ volatile("" : "+v"(c_576));  // (pinned like the others, except where registers are scarcest)
     double c_169 = 169.0;                          // 13^2: tier test k^2 >= 169 n
     if (K32) __asm__ volatile("" : "+v"(c_169));   // (pinned like the others, except in the K > 32 variant: registers)
     uint64_t sweeps_done = 0;
@@ -424,6 +431,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 // the other three uniforms -- it reads back from the hand-off buffer / draws again itself (counter-based):
                 // some ten vector registers less across the step loop.
                 const uint32_t v_l = hand[0 * kWave + lane];
+                new_lab[lane] = 0xffu;
                 const uint32_t deg_l = hand[2 * kWave + lane], r_l = hand[3 * kWave + lane];
                 const int piv_l = (int)hand[4 * kWave + lane];
                 double ud_R = 0., ud_tgt = 0., ud_acc = 0.;
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 // ---- any step (all the rare cases included): the definition the hot path below specialises ----
                 auto step_general = [&](uint32_t q, double T) {
                     auto handed = [&](uint32_t word) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)hand[word * kWave + q]); };
-                    const uint32_t v = handed(0), deg = handed(2), r = handed(3);
+                    const uint32_t deg = handed(2), r = handed(3);
                     const uint32_t r_loc = r - own_base;
                     // the step's four uniforms (:619-628, :57), drawn again here: wave-uniform values
                     const uint64_t gs_q = sweeps_total * (uint64_t)n + node_base + vi0 + q;
@@ -613,7 +621,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         if (lane == 0) {
                             eta_any_wr(r_loc, deg, (uint32_t)(eta_r - 1));
                             eta_any_wr(s_loc, deg, (uint32_t)(eta_s + 1));
-                            labels[v] = (uint8_t)s;
+                            new_lab[q] = (uint8_t)s;
                         }
                         mr_own += (lb == s_loc ? ideg : 0) - (lb == r_loc ? ideg : 0);
                         nr_own += (lb == s_loc ? 1 : 0) - (lb == r_loc ? 1 : 0);
@@ -628,6 +636,11 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         new_minimum(q);  // an accepted r == s step (see new_minimum)
                     }
                     book(ok, T);
+                    // Nothing of this (rare) step may still be in flight when the hot loop goes on: the register allocator reuses
+                    // the destination registers of its gathers for per-pass values of the hot step, and the compiler's wait-count
+                    // bookkeeping, which merges every path into the loop head, would otherwise make EVERY hot pass wait for all
+                    // outstanding vector memory operations -- i.e. for the label store of the pass before -- at its top.
+                    __builtin_amdgcn_s_waitcnt(0);
                 };
 
                 // ---- the 64 steps.  Hot path: 1 <= deg <= 255, target drawn from column m[.][t], T > 0 ----
@@ -770,12 +783,11 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         if (b_acc == 0 || n_r_r == 1) return;  // (:467-471: veto after the draw)
                     }
                     // ---- apply_mcmc_moves, blockmodel.cc:461-503 ----
-                    const uint32_t v = readlane(v_l, q);
                     wfence();
                     if (lane == 0) {
                         eta_l[eta_at(r_loc, deg)] = (uint32_t)(eta_r - 1);
                         eta_l[eta_at(s_loc, deg)] = (uint32_t)(eta_s + 1);
-                        labels[v] = (uint8_t)s;
+                        new_lab[q] = (uint8_t)s;
                         cum_l0 += dS;  // :500
                         acc_l0 += 1;
                     }
@@ -816,7 +828,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const int sel = (int)(qs << 2);
                     FSTAMP_STEP(0);
                     const uint32_t prop = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)prop_l);
-                    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)v_l);
                     const double u_acc = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(ud_acc)),
                                                           __builtin_amdgcn_ds_bpermute(sel, __double2loint(ud_acc)));
                     const uint32_t packA = readlane(pack_l, q), packB = readlane(pack_l, qB);
@@ -981,7 +992,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         }
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000003000000030ull))  // lanes 4, 5: eta_r - 1, eta_s + 1
                             eta_l[e_idx] = (uint32_t)wr_eta;
-                        if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000000100000001ull)) labels[v] = (uint8_t)(own_base + s_loc);
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000000100000001ull)) new_lab[qs] = (uint8_t)(own_base + s_loc);
                         mr_own += (dmA & (int)mA) + (dmB & (int)mB);
                         nr_own += (dlA & (int)mA) + (dlB & (int)mB);
                         // :500, in step order; a step that does not move adds +0.0 (x + 0.0 is x: the running sum is never -0.0)
@@ -1009,7 +1020,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t qs = q + (half & (0u - pairable));
                     const int sel = (int)(qs << 2);
                     const uint32_t prop = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)prop_l);
-                    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)v_l);
                     const double u_acc = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(ud_acc)),
                                                           __builtin_amdgcn_ds_bpermute(sel, __double2loint(ud_acc)));
                     const uint32_t packA = readlane(pack_l, q), packB = readlane(pack_l, qB);
@@ -1163,7 +1173,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         }
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000003000000030ull))  // lanes 4, 5: eta_r - 1, eta_s + 1
                             eta_l[e_idx] = (uint32_t)(ee + ((int)(lh & 1u) * 2 - 1));
-                        if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000000100000001ull)) labels[v] = (uint8_t)(own_base + s_loc);
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000000100000001ull)) new_lab[qs] = (uint8_t)(own_base + s_loc);
                         mr_own += (dmA & (int)mA) + (dmB & (int)mB);
                         nr_own += (dlA & (int)mA) + (dlB & (int)mB);
                         cum_l0 += __hiloint2double(dS_A_hi & (int)mA, dS_A_lo & (int)mA);
@@ -1190,7 +1200,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t qs = q + min(row, nst - 1u);  // (rows past nst repeat the last step; their results are ignored)
                     const int sel = (int)(qs << 2);
                     const uint32_t prop = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)prop_l);
-                    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)v_l);
                     const uint32_t pack = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)pack_l);
                     const double u_acc = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(ud_acc)),
                                                           __builtin_amdgcn_ds_bpermute(sel, __double2loint(ud_acc)));
@@ -1339,7 +1348,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         }
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0030003000300030ull))  // lanes 4, 5 of a row: eta_r - 1, eta_s + 1
                             eta_l[e_idx] = (uint32_t)(ee + ((int)(lb & 1u) * 2 - 1));
-                        if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0001000100010001ull)) labels[v] = (uint8_t)(own_base + s_loc);
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0001000100010001ull)) new_lab[qs] = (uint8_t)(own_base + s_loc);
                         // the register copies of m_r / n_r, sum dS (:500) and the early-stop bookkeeping, in step order
 #pragma unroll
                         for (uint32_t g = 0; g < 4u; ++g) {
@@ -1384,7 +1393,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t qs = q + min(grp, nst - 1u);
                     const int sel = (int)(qs << 2);
                     const uint32_t prop = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)prop_l);
-                    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)v_l);
                     const uint32_t pack = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)pack_l);
                     const double u_acc = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(ud_acc)),
                                                           __builtin_amdgcn_ds_bpermute(sel, __double2loint(ud_acc)));
@@ -1518,7 +1526,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         }
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x3030303030303030ull))  // lanes 4, 5 of a group: eta_r - 1, eta_s + 1
                             eta_l[e_idx] = (uint32_t)(ee + ((int)(lb & 1u) * 2 - 1));
-                        if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0101010101010101ull)) labels[v] = (uint8_t)(own_base + s_loc);
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0101010101010101ull)) new_lab[qs] = (uint8_t)(own_base + s_loc);
 #pragma unroll
                         for (uint32_t g = 0; g < 8u; ++g) {
                             if ((moved >> g) & 1u) {
@@ -1594,6 +1602,11 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     for (uint32_t q = 0; q < cnt; ++q) step(std::true_type{}, q);
                 } else {
                     for (uint32_t q = 0; q < cnt; ++q) step(std::false_type{}, q);
+                }
+                {  // the chunk's label stores (see new_lab)
+                    wfence();
+                    const uint32_t moved_to = new_lab[lane];
+                    if (moved_to != 0xffu) labels[v_l] = (uint8_t)moved_to;
                 }
                 if (track_min != 0u) {
                     wfence();
@@ -1679,7 +1692,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
 size_t sweep_fast_lds_bytes(uint32_t ka, uint32_t kb, uint32_t maxdeg, bool eta_in_lds, uint32_t eta_window) {
     const uint32_t K = ka + kb, D = maxdeg + 1, S = kb | 1u;
     const size_t dwords = (size_t)ka * S + (eta_in_lds ? (size_t)K * D : (size_t)std::max(ka, kb) * eta_window) +
-                          2 * (size_t)kWave * (kHistStride / 4) + 2 * (size_t)kHandWords * kWave + kWave + 4 + 10;
+                          2 * (size_t)kWave * (kHistStride / 4) + 2 * (size_t)kHandWords * kWave + kWave + 4 + 10 + 16;
     // the step reads m[.][lane] for all 64 lanes whatever ka, kb are (idle lanes are masked after the read):
     // dword index <= 63 * S + 63 must be inside the allocation
     const size_t reach = 63 * (size_t)S + 64;
