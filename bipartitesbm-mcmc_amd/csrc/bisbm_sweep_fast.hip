@@ -905,14 +905,13 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     uint32_t flags_pin = flags;
                     __asm__ volatile("" : "+s"(flags_pin));
                     (void)flags_pin;
-                    // ... and so is everything of apply_mcmc_moves that does not depend on the verdicts: the values to be written
-                    // and the per-lane changes of m_r / n_r, to be masked by the movers afterwards
                     int dlA = (int)min(lb ^ r_locA, 1u) - (int)min(lb ^ s_locA, 1u);  // +1 on lane s, -1 on lane r
                     int dlB = (int)min(lb ^ r_locB, 1u) - (int)min(lb ^ s_locB, 1u);
                     int dmA = __mul24((int)degA, dlA), dmB = __mul24((int)degB, dlB);
+                    __asm__ volatile("" : "+v"(dlA), "+v"(dlB), "+v"(dmA), "+v"(dmB));
+                    // (what apply_mcmc_moves will write, worked out while the table gathers are in flight and pinned there)
                     int wr_rt = m_rt_raw - k, wr_st = m_st_raw + k, wr_eta = ee + ((int)(lb & 1u) * 2 - 1);
-                    __asm__ volatile("" : "+v"(dlA), "+v"(dlB), "+v"(dmA), "+v"(dmB), "+v"(wr_rt), "+v"(wr_st), "+v"(wr_eta));
-
+                    __asm__ volatile("" : "+v"(wr_rt), "+v"(wr_st), "+v"(wr_eta));
                     const double a0 = k * (m_st + eps) * inv_blk;
                     const double a1 = k * (m_rt - k + eps) * inv_blk;
                     double accu0, accu1;  // lanes 16..31: step q, lanes 48..63: step q + 1
