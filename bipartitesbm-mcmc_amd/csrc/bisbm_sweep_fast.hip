@@ -103,7 +103,7 @@ __device__ __forceinline__ uint32_t smin(uint32_t x, uint32_t y) {
 }
 
 constexpr uint32_t kHistStride = 68;  // bytes per k_v row: 64 counters + pad (17 dwords: odd, conflict-free)
-constexpr uint32_t kHandWords = 5;    // v, row begin, degree, own label, pivot label
+constexpr uint32_t kHandWords = 9;    // v, row begin, degree, own label, pivot label, proposal word, packed hot-step inputs, accept uniform (2)
 constexpr uint32_t kRowCap = 255;     // longest row the feeder walks (a k_v counter is a byte); longer rows: per-step side path
 
 // a double constant held in a vector register pair for the whole kernel (64-bit literals are not encodable
@@ -166,6 +166,11 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     // the pass is still in flight at the top of the next one, where the compiler's wait for "all vector memory operations"
     // (it cannot prove that no load into a reused register is pending) then waits for it.
     uint8_t* const new_lab = (uint8_t*)(lds32 + o_flag + 8);
+    // m_r of the phase's OPPOSITE type (frozen during the phase), published by the stepping wave when the phase begins: the
+    // feeder wave works out the proposals' random part with it (prepare)
+    int32_t* const mr_pub = (int32_t*)(lds32 + o_flag + 24);
+    // 1 / T of the chunk's 64 steps (cooling schedules), written by the stepping wave when the chunk begins and read per pass
+    double* const invT_buf = (double*)(lds32 + o_flag + 88);
     if (lane == 0) role[wave_in_wg] = ((xcc_id & 0xfu) << 10) | ((hw_id >> 6) & 0x3fcu) | ((hw_id >> 4) & 3u);
     __syncthreads();
     if (wave_in_wg == 0 && lane == 0) {
@@ -346,6 +351,21 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
             const unsigned long long lanes_koth64_hi = __builtin_amdgcn_ballot_w64((lane & 31u) + 32u < k_oth);  // two opposite-type blocks
             const uint32_t node_other0 = TB ? 0u : na;  // some node of the opposite type: what idle slots of the walk load
 
+            // The proposal's random part (blockmodel.cc:619-628), worked out for all 64 steps of a chunk at once (lane = step) by
+            // the feeder wave: the opposite type's labels and m_r are frozen during the phase, so the R test (:622-624) and the
+            // inverse-CDF target x do not depend on the moves made inside the chunk.  Bit 31 set: uniform random block (low
+            // bits); clear: x, to be looked up in the current column m[.][t] at step time.
+            auto draw_target = [&](int32_t mrt, double u_R, double u_tgt) -> uint32_t {
+                if (u_R * (mrt + epsK) < epsK) {  // :622-624
+                    uint32_t sR = (uint32_t)(u_tgt * Kd);
+                    if (sR >= K) sR = K - 1;
+                    return 0x80000000u | sR;
+                }
+                uint32_t x = (uint32_t)(u_tgt * (double)mrt);  // m_r < 2^31
+                if (x >= (uint32_t)mrt) x = (uint32_t)mrt - 1u;
+                return x;
+            };
+
             // ---- feeder wave: everything of chunk c that does not depend on the chain's block state ----
             auto prepare = [&](uint32_t c) {
                 const uint32_t vi0 = c * kWave;
@@ -417,6 +437,28 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 hand[2 * kWave + lane] = deg_l;
                 hand[3 * kWave + lane] = r_l;
                 hand[4 * kWave + lane] = (uint32_t)piv_l;
+                // Per-lane inputs of the hot step.  Bit 31 of the proposal word sends the step down the general path: uniform
+                // random target, a single own block, empty or over-long rows, T == 0, a degree outside the eta window.
+                // (the other three uniforms of step vi0 + lane are drawn here, after the walk -- counter-based: the draw for the
+                // pivot above is simply repeated -- so that they do not occupy registers during it)
+                double ud_R = 0., ud_tgt = 0., ud_acc = 0.;
+                if (lane < cnt) {
+                    const uint64_t gs = sweeps_total * (uint64_t)n + node_base + vi0 + lane;
+                    const U4 A = phx_draw(p.seed, chain_gid, PHX_STEP_A, gs);
+                    const U4 B = phx_draw(p.seed, chain_gid, PHX_STEP_B, gs);
+                    ud_R = u53(A.z, A.w);
+                    ud_tgt = u53(B.x, B.y);
+                    ud_acc = u53(B.z, B.w);
+                }
+                const uint32_t tloc_l = ((uint32_t)piv_l - oth_base) & 63u;
+                const uint32_t rloc_l = r_l - own_base;
+                uint32_t prop_l = draw_target(mr_pub[tloc_l], ud_R, ud_tgt);
+                if (k_own == 1u || deg_l == 0u || deg_l > kRowCap || (CT && T_const == 0.)) prop_l |= 0x80000000u;
+                if (!EL && deg_l - eta_lo >= eta_w) prop_l |= 0x80000000u;  // eta[.][deg] is not in the LDS window
+                hand[5 * kWave + lane] = prop_l;
+                // degree (<= 255 in the hot step), own block and pivot block in one word (one cross-lane move per pass)
+                hand[6 * kWave + lane] = (deg_l & 255u) | ((rloc_l & 63u) << 8) | (tloc_l << 16);
+                *(double*)&hand[7 * kWave + 2 * lane] = ud_acc;  // (words 7, 8: the 64 accept uniforms as doubles)
                 wfence();
             };
 
@@ -426,28 +468,27 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 const uint32_t cnt = (n_own - vi0) < (uint32_t)kWave ? (n_own - vi0) : (uint32_t)kWave;
                 const uint8_t* const hist8_cur = (const uint8_t*)(hist8_base + (c & 1u) * kWave * (kHistStride / 4));
                 const uint32_t* const hand = hand_base + (c & 1u) * kHandWords * kWave;
-                // Per-lane data of the chunk that lives through its steps: the node, the accept uniform, the packed inputs of the
-                // hot step (below).  Everything else the rare general step needs -- row begin, full degree, own and pivot label,
-                // the other three uniforms -- it reads back from the hand-off buffer / draws again itself (counter-based):
-                // some ten vector registers less across the step loop.
-                const uint32_t v_l = hand[0 * kWave + lane];
+                // Per-lane data of the chunk that lives through its steps, all of it handed over by the feeder wave: the node, the
+                // proposal word, the packed inputs of the hot step, the accept uniform.  Everything else the rare general step
+                // needs -- row begin, full degree, own and pivot label, the other three uniforms -- it reads back from the hand-off
+                // buffer / draws again itself (counter-based).
+                // (Only the packed word, which the passes fetch with v_readlane, is kept in a register through the chunk; the
+                // proposal word, the accept uniform and 1 / T are read from LDS at a per-half / per-row address by every pass.)
                 new_lab[lane] = 0xffu;
-                const uint32_t deg_l = hand[2 * kWave + lane], r_l = hand[3 * kWave + lane];
-                const int piv_l = (int)hand[4 * kWave + lane];
-                double ud_R = 0., ud_tgt = 0., ud_acc = 0.;
-                if (lane < cnt) {  // the uniforms of step vi0 + lane (counter-based: any lane can draw them)
-                    const uint64_t gs = sweeps_total * (uint64_t)n + node_base + vi0 + lane;
-                    const U4 A = phx_draw(p.seed, chain_gid, PHX_STEP_A, gs);
-                    const U4 B = phx_draw(p.seed, chain_gid, PHX_STEP_B, gs);
-                    ud_R = u53(A.z, A.w);
-                    ud_tgt = u53(B.x, B.y);
-                    ud_acc = u53(B.z, B.w);
-                }
+                const uint32_t pack_l = hand[6 * kWave + lane];
+                const unsigned long long gen_mask = __builtin_amdgcn_ballot_w64((int32_t)hand[5 * kWave + lane] < 0);  // steps that need the general path
+                auto prop_of = [&](uint32_t step) -> uint32_t { return hand[5 * kWave + step]; };
+                auto u_acc_of = [&](uint32_t step) -> double { return *(const double*)&hand[7 * kWave + 2 * step]; };
                 // the temperatures of the 64 steps (:84), lane = step: one table read or one pow / log per lane per chunk
                 double T_l = T_const;
                 if (!CT) T_l = temperature_tabled(p, sweep_step0 + node_base + vi0 + lane);
                 const double invT_l = 1.0 / T_l;  // (T == 0: not used, the step is decided by the sign of dS)
                 if (!CT && invT_l == INFINITY) T_l = 0.;  // (see T_const)
+                if (!CT) {
+                    invT_buf[lane] = invT_l;
+                    wfence();
+                }
+                auto invT_of = [&](uint32_t step) -> double { return invT_buf[step]; };
                 // (the general step evaluates its temperature again -- a table read at a wave-uniform index -- instead of keeping
                 // the chunk's 64 temperatures alive through the step loop for it)
                 auto T_of_step = [&](uint32_t q) -> double {
@@ -455,30 +496,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double T = temperature_tabled(p, sweep_step0 + node_base + vi0 + q);
                     return 1.0 / T == INFINITY ? 0. : T;
                 };
-                // The proposal's random part (blockmodel.cc:619-628) for all 64 steps at once, lane = step: the
-                // opposite type's labels and m_r are frozen during the phase, so the R test (:622-624) and the
-                // inverse-CDF target x do not depend on the moves made inside the chunk.  Bit 31 set: uniform
-                // random block (low bits); clear: x, to be looked up in the current column m[.][t] at step time.
-                auto draw_target = [&](int32_t mrt, double u_R, double u_tgt) -> uint32_t {
-                    if (u_R * (mrt + epsK) < epsK) {  // :622-624
-                        uint32_t sR = (uint32_t)(u_tgt * Kd);
-                        if (sR >= K) sR = K - 1;
-                        return 0x80000000u | sR;
-                    }
-                    uint32_t x = (uint32_t)(u_tgt * (double)mrt);  // m_r < 2^31
-                    if (x >= (uint32_t)mrt) x = (uint32_t)mrt - 1u;
-                    return x;
-                };
-                // Per-lane inputs of the hot step.  prop_l bit 31 sends the step down the general path: uniform
-                // random target, a single own block, empty or over-long rows, T == 0, small graphs.
-                const uint32_t tloc_l = ((uint32_t)piv_l - oth_base) & 63u;
-                const uint32_t rloc_l = r_l - own_base;
-                uint32_t prop_l = draw_target(__builtin_amdgcn_ds_bpermute((int)(tloc_l << 2), mr_oth), ud_R, ud_tgt);
-                // per-step inputs of the hot step: degree (<= 255 there), own block and pivot block in one word (one cross-lane move)
-                const uint32_t pack_l = (deg_l & 255u) | ((rloc_l & 63u) << 8) | (tloc_l << 16);
-                if (k_own == 1u || deg_l == 0u || deg_l > kRowCap || (CT && T_const == 0.)) prop_l |= 0x80000000u;
-                if (!EL && deg_l - eta_lo >= eta_w) prop_l |= 0x80000000u;  // eta[.][deg] is not in the LDS window
-
                 // anneal()'s bookkeeping, metropolis_hasting.cc:85-94, see emin_l0 above
                 const unsigned long long below1_mask =
                     track_min != 0u ? __builtin_amdgcn_ballot_w64(lane < cnt && T_l < 1.) : 0ull;
@@ -655,7 +672,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     constexpr bool TM = decltype(tm)::value;
                     const double T = CT ? T_const : readlane(T_l, q);  // :84
                     FSTAMP_STEP(0);
-                    const uint32_t prop = readlane(prop_l, q);
+                    const uint32_t prop = (uint32_t)__builtin_amdgcn_readfirstlane((int)prop_of(q));
                     if (__builtin_expect((int32_t)prop < 0, 0)) {
                         step_general(q, T);
                         return;
@@ -771,9 +788,9 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     } else {
                         // accept (:47-61): u accu0 < accu1 exp(-dS/T), decided on a 1e-7-accurate exponential unless
                         // the two sides are within 1e-5 of each other (then the exact one decides)
-                        const double z = -dS * (CT ? invT_const : readlane(invT_l, q));
+                        const double z = -dS * (CT ? invT_const : invT_of(q));
                         const double est = accu1 * exp2_filter(z * c_l2e);
-                        const double lhs = readlane(ud_acc, q) * accu0;
+                        const double lhs = u_acc_of(q) * accu0;
                         const unsigned long long b_lt = __builtin_amdgcn_ballot_w64(lhs < est);
                         const unsigned long long b_far = __builtin_amdgcn_ballot_w64(fabs(lhs - est) > c_tol * est);
                         FSTAMP_STEP(7);
@@ -827,9 +844,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                                                                          // select of uniform values goes through the vector unit and back)
                     const int sel = (int)(qs << 2);
                     FSTAMP_STEP(0);
-                    const uint32_t prop = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)prop_l);
-                    const double u_acc = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(ud_acc)),
-                                                          __builtin_amdgcn_ds_bpermute(sel, __double2loint(ud_acc)));
+                    const uint32_t prop = prop_of(qs);
+                    const double u_acc = u_acc_of(qs);
                     const uint32_t packA = readlane(pack_l, q), packB = readlane(pack_l, qB);
                     const uint32_t r_locA = (packA >> 8) & 63u, r_locB = (packB >> 8) & 63u;
                     const uint32_t degA = packA & 255u, degB = packB & 255u, t_locA = packA >> 16, t_locB = packB >> 16;
@@ -953,8 +969,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     FSTAMP_STEP(6);
                     // accept (:47-61) in the lanes that hold the sums; bit 31 is step q's verdict, bit 63 step q + 1's
                     double invT = invT_const;
-                    if (!CT) invT = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(invT_l)),
-                                                     __builtin_amdgcn_ds_bpermute(sel, __double2loint(invT_l)));
+                    if (!CT) invT = invT_of(qs);
                     const double z = -dS * invT;
                     const double est = accu1 * exp2_filter(z * c_l2e);
                     const double lhs = u_acc * accu0;
@@ -1018,9 +1033,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t qB = q + pairable;
                     const uint32_t qs = q + (half & (0u - pairable));
                     const int sel = (int)(qs << 2);
-                    const uint32_t prop = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)prop_l);
-                    const double u_acc = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(ud_acc)),
-                                                          __builtin_amdgcn_ds_bpermute(sel, __double2loint(ud_acc)));
+                    const uint32_t prop = prop_of(qs);
+                    const double u_acc = u_acc_of(qs);
                     const uint32_t packA = readlane(pack_l, q), packB = readlane(pack_l, qB);
                     const uint32_t r_locA = (packA >> 8) & 63u, r_locB = (packB >> 8) & 63u;
                     const uint32_t degA = packA & 255u, degB = packB & 255u, t_locA = packA >> 16, t_locB = packB >> 16;
@@ -1132,8 +1146,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     d = d + ((L1_1 + L2_1) - (L3_1 + L4_1));
                     const double dS = butterfly_rows32(d);
                     double invT = invT_const;
-                    if (!CT) invT = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(invT_l)),
-                                                     __builtin_amdgcn_ds_bpermute(sel, __double2loint(invT_l)));
+                    if (!CT) invT = invT_of(qs);
                     const double z = -dS * invT;
                     const double est = accu1 * exp2_filter(z * c_l2e);
                     const double lhs = u_acc * accu0;
@@ -1198,10 +1211,9 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     constexpr bool TM = decltype(tm)::value;
                     const uint32_t qs = q + min(row, nst - 1u);  // (rows past nst repeat the last step; their results are ignored)
                     const int sel = (int)(qs << 2);
-                    const uint32_t prop = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)prop_l);
+                    const uint32_t prop = prop_of(qs);
                     const uint32_t pack = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)pack_l);
-                    const double u_acc = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(ud_acc)),
-                                                          __builtin_amdgcn_ds_bpermute(sel, __double2loint(ud_acc)));
+                    const double u_acc = u_acc_of(qs);
                     const uint32_t deg = pack & 255u, r_loc = (pack >> 8) & 63u, t_loc = pack >> 16;
                     const int k = (int)hist8_cur[qs * kHistStride + lb];
                     const uint32_t a_rt = mq_at(r_loc, lb);
@@ -1300,8 +1312,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double dS = butterfly_rows16(d);
                     // accept (:47-61), per row
                     double invT = invT_const;
-                    if (!CT) invT = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(invT_l)),
-                                                     __builtin_amdgcn_ds_bpermute(sel, __double2loint(invT_l)));
+                    if (!CT) invT = invT_of(qs);
                     const double z = -dS * invT;
                     const double est = accu1 * exp2_filter(z * c_l2e);
                     const double lhs = u_acc * accu0;
@@ -1367,7 +1378,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     return (uint32_t)__builtin_popcount(commit);
                 };
                 auto quad_loop = [&](auto tm) {
-                    const unsigned long long gen_mask = __builtin_amdgcn_ballot_w64((int32_t)prop_l < 0);
                     uint32_t q = 0;
                     acc_chunk = 0;
                     while (q < cnt) {
@@ -1391,10 +1401,9 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     constexpr bool TM = decltype(tm)::value;
                     const uint32_t qs = q + min(grp, nst - 1u);
                     const int sel = (int)(qs << 2);
-                    const uint32_t prop = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)prop_l);
+                    const uint32_t prop = prop_of(qs);
                     const uint32_t pack = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)pack_l);
-                    const double u_acc = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(ud_acc)),
-                                                          __builtin_amdgcn_ds_bpermute(sel, __double2loint(ud_acc)));
+                    const double u_acc = u_acc_of(qs);
                     const uint32_t deg = pack & 255u, r_loc = (pack >> 8) & 63u, t_loc = pack >> 16;
                     const int k = (int)hist8_cur[qs * kHistStride + lb];
                     const uint32_t a_rt = mq_at(r_loc, lb);
@@ -1490,8 +1499,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     d = d + lq * sign_q;
                     const double dS = butterfly_groups8(d);
                     double invT = invT_const;
-                    if (!CT) invT = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(invT_l)),
-                                                     __builtin_amdgcn_ds_bpermute(sel, __double2loint(invT_l)));
+                    if (!CT) invT = invT_of(qs);
                     const double z = -dS * invT;
                     const double est = accu1 * exp2_filter(z * c_l2e);
                     const double lhs = u_acc * accu0;
@@ -1544,7 +1552,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     return (uint32_t)__builtin_popcount(commit);
                 };
                 auto oct_loop = [&](auto tm) {
-                    const unsigned long long gen_mask = __builtin_amdgcn_ballot_w64((int32_t)prop_l < 0);
                     uint32_t q = 0;
                     acc_chunk = 0;
                     while (q < cnt) {
@@ -1561,7 +1568,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 };
                 // steps that need the general path (bit 31 of prop_l) go one at a time
                 auto pair_loop = [&](auto tm) {
-                    const unsigned long long gen_mask = __builtin_amdgcn_ballot_w64((int32_t)prop_l < 0);
                     uint32_t q = 0;
                     acc_chunk = 0;
                     while (q < cnt) {
@@ -1605,7 +1611,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 {  // the chunk's label stores (see new_lab)
                     wfence();
                     const uint32_t moved_to = new_lab[lane];
-                    if (moved_to != 0xffu) labels[v_l] = (uint8_t)moved_to;
+                    if (moved_to != 0xffu) labels[hand[0 * kWave + lane]] = (uint8_t)moved_to;
                 }
                 if (track_min != 0u) {
                     wfence();
@@ -1615,6 +1621,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
             };
 
             // chunk pipeline: the feeder is one chunk ahead; one workgroup barrier per chunk
+            if (is_main) mr_pub[lane] = mr_oth;
+            __syncthreads();
             if (!is_main) prepare(0);
             __syncthreads();
             for (uint32_t c = 0; c < n_chunks; ++c) {
@@ -1691,7 +1699,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
 size_t sweep_fast_lds_bytes(uint32_t ka, uint32_t kb, uint32_t maxdeg, bool eta_in_lds, uint32_t eta_window) {
     const uint32_t K = ka + kb, D = maxdeg + 1, S = kb | 1u;
     const size_t dwords = (size_t)ka * S + (eta_in_lds ? (size_t)K * D : (size_t)std::max(ka, kb) * eta_window) +
-                          2 * (size_t)kWave * (kHistStride / 4) + 2 * (size_t)kHandWords * kWave + kWave + 4 + 10 + 16;
+                          2 * (size_t)kWave * (kHistStride / 4) + 2 * (size_t)kHandWords * kWave + kWave + 4 + 10 + 16 + 64 + 128;
     // the step reads m[.][lane] for all 64 lanes whatever ka, kb are (idle lanes are masked after the read):
     // dword index <= 63 * S + 63 must be inside the allocation
     const size_t reach = 63 * (size_t)S + 64;

@@ -1,7 +1,9 @@
 // Probe: cost of handing a result from one wave of a workgroup to another through LDS (write payload + sequence word,
 // the other wave polls the sequence word), as a ping-pong between the two waves of every workgroup at the sweep
-// kernel's launch shape (1024 workgroups of 128 threads, 4 per CU).  Prints 100 MHz ticks and shader cycles per ROUND TRIP
-// (two hand-offs), with the poll loop written the way a stepping wave would write it (ds_read -> readfirstlane -> branch).
+// kernel's launch shape (1024 workgroups of 128 threads, 4 per CU).  Prints s_memtime ticks per ROUND TRIP (two hand-offs), with
+// the poll loop written the way a stepping wave would write it (ds_read -> readfirstlane -> branch).  On this chip s_memtime
+// advances at about the shader clock (the sweep kernel's stage stamps add up to its measured time per step at ~2.3 GHz), so
+// a tick is a cycle.
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/wave_handoff tools/probe/wave_handoff.hip && /tmp/wave_handoff
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -61,9 +63,9 @@ int main() {
                 same_simd += s[2 * i] == s[2 * i + 1];
             }
             std::sort(per.begin(), per.end());
-            printf("grid %4d payload %d words: round trip (two hand-offs) median %.2f ticks = %.0f cycles at 2.35 GHz, min %.2f, max %.2f"
-                   " ticks; workgroups with both waves on one SIMD: %d\n",
-                   grid, payload, per[grid / 2], per[grid / 2] * 23.5, per[0], per[grid - 1], same_simd);
+            printf("grid %4d payload %d words: round trip (two hand-offs) median %.1f cycles, min %.1f, max %.1f; workgroups with both"
+                   " waves on one SIMD: %d\n",
+                   grid, payload, per[grid / 2], per[0], per[grid - 1], same_simd);
         }
     }
     return 0;
