@@ -219,9 +219,10 @@ def test_deep_passes_at_full_size(k, monkeypatch):
 
 # ------------------------------------------------------------------ BASELINE configs[4]: per-GPU shape
 def test_config5_shape_properties():
-    """N_a = N_b = 2e6, E = 5e7, Ka = Kb = 64 (the K > 32 variant of the production kernel, eta in HBM), 16 chains:
-    one sweep keeps the incremental state equal to a recount, block sizes sum to N, and the sum of accepted dS equals
-    the change of the full description length."""
+    """N_a = N_b = 2e6, E = 5e7, Ka = Kb = 64 (the K > 32 variant of the production kernel: two steps per pass with two
+    blocks per lane, a window of eta in LDS), 256 chains -- the per-GPU shape of BASELINE configs[4] at a quarter of its
+    chains: a sweep at constant T and a sweep under a cooling schedule keep the incremental state equal to a recount, block
+    sizes sum to N, and the sum of accepted dS equals the change of the full description length, in every chain."""
     na = nb = 2_000_000
     ka = kb = 64
     E = 50_000_000
@@ -229,7 +230,7 @@ def test_config5_shape_properties():
     rowptr, col = B.edge_to_adj((a, b), na + nb)
     del a, b
     labels = SYN.contiguous_labels(na, nb, ka, kb)
-    chains = 16
+    chains = 256
     g = gpu_model(rowptr, col, na, nb, ka, kb, 1.0, labels, n_chains=chains, rng="philox", seed=5)
     g.shuffle_bisbm()
     s0 = g.entropy()
@@ -239,19 +240,26 @@ def test_config5_shape_properties():
     cum = g.get_entropy()
     assert np.allclose(s1 - s0, cum, rtol=1e-9, atol=1e-6 * np.abs(cum).max())
     picks = (0, 7, chains - 1)
+    labs_after_first = [g.get_memberships(c) for c in picks]
+    rates = B.MetropolisHasting().anneal(g, "exponential", [1.5, 0.9999999], na + nb, BIG)  # (the cooling-schedule variant)
+    assert ((rates > 0.2) & (rates <= 1.0)).all()
+    s2 = g.entropy()
+    cum2 = g.get_entropy()
+    assert np.allclose(s2 - s0, cum2, rtol=1e-9, atol=1e-6 * np.abs(cum2).max())
     before = [(g.get_m(c), g.get_m_r(c), g.get_n_r(c), g.get_eta_rk_(c)) for c in picks]
     labs = [g.get_memberships(c) for c in picks]
+    n_r_all = [g.get_n_r(c) for c in range(0, chains, 17)]
+    assert all(x.sum() == na + nb and (x > 0).all() for x in n_r_all)
     g.init_bisbm()  # recount from the labels
     for (m, m_r, n_r, eta), c, lab in zip(before, picks, labs):
         assert (g.get_m(c) == m).all() and (g.get_m_r(c) == m_r).all()
         assert (g.get_n_r(c) == n_r).all() and (g.get_eta_rk_(c) == eta).all()
         assert n_r.sum() == na + nb and m_r.sum() == 2 * E
         assert (np.bincount(lab, minlength=ka + kb) == n_r).all()
-    ms, updates = g.last_sweep_timing()
-    assert updates == chains * (na + nb) and ms > 0
-    # chains are distinct (keyed by chain id) and reproducible: chain 3 re-run alone gives the same labels
+    assert all((g.get_n_r(c) == x).all() for c, x in zip(range(0, chains, 17), n_r_all))
+    # chains are distinct (keyed by chain id) and reproducible: chain 7 re-run alone gives the same labels
     assert (labs[0] != labs[1]).any()
     solo = gpu_model(rowptr, col, na, nb, ka, kb, 1.0, labels, n_chains=1, rng="philox", seed=5, first_chain_id=7)
     solo.shuffle_bisbm()
     B.MetropolisHasting().anneal(solo, "constant", [1.0], na + nb, BIG)
-    assert (solo.get_memberships(0) == labs[1]).all()
+    assert (solo.get_memberships(0) == labs_after_first[1]).all()
