@@ -1102,27 +1102,33 @@ hipError_t launch_merge_relabel(uint8_t* labels, bool wide, size_t label_stride,
 //   compat: bit (offset of b + i) of the host-shuffled splitter_ of that trial (std::shuffle on the chain's engine),
 //   Philox: feistel(key(b, j), n_b)(i) >= floor(n_b / 2), key = Philox(seed, chain, PHX_SPLIT, epoch << 32 | b << 16 | j).
 // ------------------------------------------------------------------------------------------
+// LabelT: bytes, or two bytes while the handle is wide (more than 256 blocks).  HBM: the per-label counters live in p.rank_base
+// ([chain][K], zeroed by the host) instead of 256 LDS words.
+template <class LabelT, bool HBM>
 __global__ __launch_bounds__(kWave) void split_rank_kernel(SplitParams p) {
-    __shared__ uint32_t base[256];
+    __shared__ uint32_t base_lds[256];
     const uint32_t chain = blockIdx.x, lane = threadIdx.x;
-    for (uint32_t i = lane; i < 256; i += kWave) base[i] = 0;
-    __syncthreads();
+    uint32_t* const base = HBM ? p.rank_base + (size_t)chain * (p.ka + p.kb) : base_lds;
+    if (!HBM) {
+        for (uint32_t i = lane; i < 256; i += kWave) base_lds[i] = 0;
+        __syncthreads();
+    }
     const uint32_t v_lo = p.type ? p.na : 0u, n_type = p.type ? p.n - p.na : p.na;
-    const uint8_t* lab = p.labels + (size_t)chain * p.label_stride + v_lo;
+    const LabelT* lab = (const LabelT*)p.labels + (size_t)chain * p.label_stride + v_lo;
     uint32_t* rank = p.rank + (size_t)chain * n_type;
     for (uint32_t t0 = 0; t0 < n_type; t0 += kWave) {
         const uint32_t i = t0 + lane;
         const bool active = i < n_type;
-        const uint32_t L = active ? lab[i] : 0xffffffffu;
+        const uint32_t L = active ? (uint32_t)lab[i] : 0xffffffffu;
         unsigned long long remaining = __ballot(active);
         while (remaining) {  // one round per distinct label among the 64 nodes
             const int leader = __ffsll((long long)remaining) - 1;
             const uint32_t cur = (uint32_t)__shfl((int)L, leader, kWave);
             const unsigned long long same = __ballot(active && L == cur);
-            if (active && L == cur) rank[i] = base[cur] + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-            __syncthreads();
-            if ((int)lane == leader) base[cur] += (uint32_t)__popcll(same);
-            __syncthreads();
+            uint32_t before = 0;  // nodes of this label seen so far (the atomic returns it: no second pass over the counter)
+            if ((int)lane == leader) before = atomicAdd(&base[cur], (uint32_t)__popcll(same));
+            before = (uint32_t)__shfl((int)before, leader, kWave);
+            if (active && L == cur) rank[i] = before + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
             remaining &= ~same;
         }
     }
@@ -1134,6 +1140,10 @@ struct SplitCut {
     uint32_t half;  // floor(n_b / 2): ranks mapped below it stay
 };
 
+// HBM = false: the counts of one (trial, chain) are gathered in LDS ([k_type][k_oth] + per-block helpers) and written out.
+// HBM = true (wide handles: the table does not fit the LDS): counted straight into the (zeroed) output with global atomics;
+// a node's cut is made on the spot from its block's key instead of being kept per block.
+template <class LabelT, bool HBM>
 __global__ __launch_bounds__(256) void split_eval_kernel(SplitParams p) {
     extern __shared__ int32_t sp_lds[];
     const uint32_t trial = p.trial0 + blockIdx.x, chain = blockIdx.y;
@@ -1141,13 +1151,42 @@ __global__ __launch_bounds__(256) void split_eval_kernel(SplitParams p) {
     const uint32_t b_lo = p.type ? p.ka : 0u, k_type = p.type ? p.kb : p.ka;
     const uint32_t t_lo = p.type ? 0u : p.ka, k_oth = p.type ? p.ka : p.kb;
     const uint32_t v_lo = p.type ? p.na : 0u, n_type = p.type ? p.n - p.na : p.na;
+    const uint32_t epoch = p.scalars[chain].split_epoch;
+    const LabelT* lab = (const LabelT*)p.labels + (size_t)chain * p.label_stride;
+    const uint32_t* rank = p.rank + (size_t)chain * n_type;
+    const uint32_t* bits = p.bits ? p.bits + ((size_t)chain * p.nm + trial) * p.bit_words : nullptr;
+    int32_t* ok = p.out_k + ((size_t)chain * p.n_trials + blockIdx.x) * k_type * k_oth;
+    int32_t* od = p.out_deg + ((size_t)chain * p.n_trials + blockIdx.x) * k_type;
+    if constexpr (HBM) {
+        const int32_t* n_r = p.n_r + (size_t)chain * K + b_lo;
+        const uint32_t* off = p.block_off + (size_t)chain * k_type;  // first position of every block in the cut bits (compat)
+        for (uint32_t i = threadIdx.x; i < n_type; i += blockDim.x) {
+            const uint32_t v = v_lo + i, r = (uint32_t)lab[v] - b_lo, nb = (uint32_t)n_r[r];
+            if (nb <= 1) continue;
+            const uint32_t rk = rank[i];
+            bool marked;
+            if (bits) {
+                const uint32_t pos = off[r] + rk;
+                marked = (bits[pos >> 5] >> (pos & 31u)) & 1u;
+            } else {
+                const uint64_t idx = ((uint64_t)epoch << 32) | ((uint64_t)(b_lo + r) << 16) | (uint64_t)trial;
+                Feistel f;
+                f.init(phx_draw(p.seed, chain_gid_of(p, chain), PHX_SPLIT, idx), nb);
+                marked = f(rk) >= nb / 2;
+            }
+            if (!marked) continue;
+            const uint32_t e0 = p.rowptr[v], e1 = p.rowptr[v + 1];
+            for (uint32_t e = e0; e < e1; ++e) atomicAdd(&ok[(size_t)r * k_oth + ((uint32_t)lab[p.col[e]] - t_lo)], 1);
+            atomicAdd(&od[r], (int32_t)(e1 - e0));
+        }
+        return;
+    }
     int32_t* const k = sp_lds;                                  // [k_type][k_oth]
     int32_t* const deg = k + k_type * k_oth;                    // [k_type]
     uint32_t* const nr = (uint32_t*)(deg + k_type);             // [k_type]
     uint32_t* const off = nr + k_type;                          // [k_type]
     SplitCut* const cut = (SplitCut*)(off + k_type + (k_type & 1u));  // [k_type]
     for (uint32_t i = threadIdx.x; i < k_type * k_oth + k_type; i += blockDim.x) k[i] = 0;
-    const uint32_t epoch = p.scalars[chain].split_epoch;
     for (uint32_t b = threadIdx.x; b < k_type; b += blockDim.x) {
         const uint32_t nb = (uint32_t)p.n_r[(size_t)chain * K + b_lo + b];
         nr[b] = nb;
@@ -1166,9 +1205,6 @@ __global__ __launch_bounds__(256) void split_eval_kernel(SplitParams p) {
         }
     }
     __syncthreads();
-    const uint8_t* lab = p.labels + (size_t)chain * p.label_stride;
-    const uint32_t* rank = p.rank + (size_t)chain * n_type;
-    const uint32_t* bits = p.bits ? p.bits + ((size_t)chain * p.nm + trial) * p.bit_words : nullptr;
     for (uint32_t i = threadIdx.x; i < n_type; i += blockDim.x) {
         const uint32_t v = v_lo + i, r = (uint32_t)lab[v] - b_lo, nb = nr[r];
         if (nb <= 1) continue;
@@ -1186,12 +1222,11 @@ __global__ __launch_bounds__(256) void split_eval_kernel(SplitParams p) {
         atomicAdd(&deg[r], (int32_t)(e1 - e0));
     }
     __syncthreads();
-    int32_t* ok = p.out_k + ((size_t)chain * p.n_trials + blockIdx.x) * k_type * k_oth;
-    int32_t* od = p.out_deg + ((size_t)chain * p.n_trials + blockIdx.x) * k_type;
     for (uint32_t i = threadIdx.x; i < k_type * k_oth; i += blockDim.x) ok[i] = k[i];
     for (uint32_t i = threadIdx.x; i < k_type; i += blockDim.x) od[i] = deg[i];
 }
 
+template <class LabelT>
 __global__ __launch_bounds__(256) void split_apply_kernel(SplitParams p) {
     __shared__ SplitCut cut;
     __shared__ uint32_t s_off, s_nb;
@@ -1213,7 +1248,7 @@ __global__ __launch_bounds__(256) void split_apply_kernel(SplitParams p) {
         }
     }
     __syncthreads();
-    uint8_t* lab = p.labels + (size_t)chain * p.label_stride;
+    LabelT* lab = (LabelT*)p.labels + (size_t)chain * p.label_stride;
     const uint32_t* rank = p.rank + (size_t)chain * n_type;
     const uint32_t* bits = p.bits ? p.bits + ((size_t)chain * p.nm + trial) * p.bit_words : nullptr;
     const uint32_t new_label = p.type ? K : p.ka;
@@ -1221,7 +1256,7 @@ __global__ __launch_bounds__(256) void split_apply_kernel(SplitParams p) {
         uint32_t L = lab[v];
         const bool own = p.type ? v >= p.na : v < p.na;
         if (!own) {
-            if (!p.type) lab[v] = (uint8_t)(L + 1);  // type-a split: the type-b labels move up by one (:434-443)
+            if (!p.type) lab[v] = (LabelT)(L + 1);  // type-a split: the type-b labels move up by one (:434-443)
             continue;
         }
         if (L != b_lo + block) continue;
@@ -1233,27 +1268,52 @@ __global__ __launch_bounds__(256) void split_apply_kernel(SplitParams p) {
         } else {
             marked = cut.f(rk) >= cut.half;
         }
-        if (marked) lab[v] = (uint8_t)new_label;
+        if (marked) lab[v] = (LabelT)new_label;
     }
 }
 
 hipError_t launch_split_rank(const SplitParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL(split_rank_kernel, dim3(p.n_chains), dim3(kWave), 0, stream, p);
+    if (p.wide)
+        hipLaunchKernelGGL((split_rank_kernel<uint16_t, true>), dim3(p.n_chains), dim3(kWave), 0, stream, p);
+    else
+        hipLaunchKernelGGL((split_rank_kernel<uint8_t, false>), dim3(p.n_chains), dim3(kWave), 0, stream, p);
     return hipGetLastError();
 }
 
 hipError_t launch_split_eval(const SplitParams& p, hipStream_t stream) {
+    if (p.wide) {  // (out_k / out_deg zeroed by the caller)
+        hipLaunchKernelGGL((split_eval_kernel<uint16_t, true>), dim3(p.n_trials, p.n_chains), dim3(256), 0, stream, p);
+        return hipGetLastError();
+    }
     const uint32_t k_type = p.type ? p.kb : p.ka, k_oth = p.type ? p.ka : p.kb;
     const size_t lds = sizeof(int32_t) * ((size_t)k_type * k_oth + 3 * (size_t)k_type + 2) + sizeof(SplitCut) * k_type;
-    hipError_t e = hipFuncSetAttribute((const void*)split_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)split_eval_kernel<uint8_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(split_eval_kernel, dim3(p.n_trials, p.n_chains), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((split_eval_kernel<uint8_t, false>), dim3(p.n_trials, p.n_chains), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
 hipError_t launch_split_apply(const SplitParams& p, hipStream_t stream) {
     const uint32_t tiles = std::min<uint32_t>((p.n + 256 * 16 - 1) / (256 * 16), 1024u);
-    hipLaunchKernelGGL(split_apply_kernel, dim3(tiles ? tiles : 1, p.n_chains), dim3(256), 0, stream, p);
+    if (p.wide)
+        hipLaunchKernelGGL(split_apply_kernel<uint16_t>, dim3(tiles ? tiles : 1, p.n_chains), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL(split_apply_kernel<uint8_t>, dim3(tiles ? tiles : 1, p.n_chains), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+// byte labels -> two-byte labels for every chain (a split takes a handle past 256 blocks)
+__global__ void labels_to_wide_kernel(const uint8_t* src, uint16_t* dst, size_t label_stride, uint32_t n) {
+    const uint8_t* s = src + (size_t)blockIdx.y * label_stride;
+    uint16_t* d = dst + (size_t)blockIdx.y * label_stride;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = (uint16_t)s[i];
+}
+
+hipError_t launch_labels_to_wide(const uint8_t* labels, uint8_t* wide_labels, size_t label_stride, uint32_t n, uint32_t n_chains,
+                                 hipStream_t stream) {
+    const uint32_t tiles = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
+    hipLaunchKernelGGL(labels_to_wide_kernel, dim3(tiles ? tiles : 1, n_chains), dim3(256), 0, stream, labels, (uint16_t*)wide_labels,
+                       label_stride, n);
     return hipGetLastError();
 }
 

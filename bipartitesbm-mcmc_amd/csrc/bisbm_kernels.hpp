@@ -163,12 +163,19 @@ struct SplitParams {
     int32_t* out_k;    // [chain][n_trials][k_type][k_oth]: edges from the marked nodes of block r to opposite block t
     int32_t* out_deg;  // [chain][n_trials][k_type]: degree sum of the marked nodes
     const uint32_t* chosen;  // apply: [chain][2] = {block (own-type index), trial}
+    // wide handles (two-byte labels, more than 256 blocks): the rank counters ([chain][K], zeroed) and, in compat mode, the
+    // first position of every block in the cut bits ([chain][k_type]) live in HBM; out_k / out_deg are zeroed by the caller
+    uint32_t wide;
+    uint32_t* rank_base;
+    const uint32_t* block_off;
 };
 constexpr uint32_t PHX_SPLIT = 6;
 
 hipError_t launch_split_rank(const SplitParams& p, hipStream_t stream);
 hipError_t launch_split_eval(const SplitParams& p, hipStream_t stream);
 hipError_t launch_split_apply(const SplitParams& p, hipStream_t stream);
+hipError_t launch_labels_to_wide(const uint8_t* labels, uint8_t* wide_labels, size_t label_stride, uint32_t n, uint32_t n_chains,
+                                 hipStream_t stream);
 
 // global id of chain `chain` of a launch
 template <class P>

@@ -1650,9 +1650,32 @@ struct MergeChain {
 int run_split(bisbm_engine* h, int type, int nm) {
     if (!h->state_ready) return fail(h, BISBM_ERR_STATE, "call bisbm_init or bisbm_shuffle before bisbm_agg_merge");
     if (nm < 1 || nm > 65535) return fail(h, BISBM_ERR_INVALID_ARG, "nm must be in [1, 65535]");
-    if (h->K + 1 > 256) return fail(h, BISBM_ERR_UNSUPPORTED, "a split would give %u blocks (splits are built for at most 256 blocks)", h->K + 1);
+    // Past 256 blocks (round 3): the handle is (or becomes) wide -- two-byte labels, the same kernels instantiated for them with
+    // their per-block tables in HBM.  The new shape must be one wide mode serves (bisbm_check_shape).
+    if (int rc = bisbm_check_shape(h->ka + (type ? 0u : 1u), h->kb + (type ? 1u : 0u), h->rng_mode)) {
+        h->err = g_create_error;
+        return rc;
+    }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!h->wide && h->K + 1 > 256) {  // 256 -> 257 blocks: the labels become two bytes first
+        uint8_t* wide_labels = nullptr;
+        HIPCHK(h, dalloc(&wide_labels, (size_t)h->n_chains * h->label_stride * 2));
+        hipError_t e = launch_labels_to_wide(h->d_labels, wide_labels, h->label_stride, (uint32_t)h->n, h->n_chains, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(wide_labels);
+            return fail(h, BISBM_ERR_HIP, "widening the labels: %s", hipGetErrorString(e));
+        }
+        (void)hipFree(h->d_labels);
+        h->d_labels = wide_labels;
+        h->wide = true;
+        if (h->d_labels_tmp) {  // (Philox mode's snapshot buffer for shuffle_bisbm: sized for the label format)
+            (void)hipFree(h->d_labels_tmp);
+            h->d_labels_tmp = nullptr;
+            HIPCHK(h, dalloc(&h->d_labels_tmp, (size_t)h->n_chains * h->label_stride * 2));
+        }
+    }
     const size_t C = h->n_chains, K = h->K, ka = h->ka, kb = h->kb;
     const size_t k_type = type ? kb : ka, k_oth = type ? ka : kb, b_lo = type ? ka : 0;
     const size_t n_type = type ? h->nb : h->na;
@@ -1672,10 +1695,10 @@ int run_split(bisbm_engine* h, int type, int nm) {
                         c, type ? 'b' : 'a');
     }
 
-    uint32_t *d_rank = nullptr, *d_bits = nullptr, *d_chosen = nullptr;
+    uint32_t *d_rank = nullptr, *d_bits = nullptr, *d_chosen = nullptr, *d_rank_base = nullptr, *d_block_off = nullptr;
     int32_t *d_out_k = nullptr, *d_out_deg = nullptr;
     auto cleanup = [&]() {
-        for (void* p : {(void*)d_rank, (void*)d_bits, (void*)d_chosen, (void*)d_out_k, (void*)d_out_deg})
+        for (void* p : {(void*)d_rank, (void*)d_bits, (void*)d_chosen, (void*)d_out_k, (void*)d_out_deg, (void*)d_rank_base, (void*)d_block_off})
             if (p) (void)hipFree(p);
     };
 #define SCHK(expr)                                                                 \
@@ -1707,6 +1730,23 @@ int run_split(bisbm_engine* h, int type, int nm) {
     sp.n_r = h->d_n_r;
     sp.scalars = h->d_scalars;
     sp.rank = d_rank;
+    sp.wide = h->wide ? 1u : 0u;
+    if (h->wide) {
+        SCHK(dalloc(&d_rank_base, C * K));
+        SCHK(hipMemsetAsync(d_rank_base, 0, sizeof(uint32_t) * C * K, h->stream));
+        sp.rank_base = d_rank_base;
+        std::vector<uint32_t> off(C * k_type);  // (compat: where a block's bits start in a trial's cut)
+        for (size_t c = 0; c < C; ++c) {
+            uint32_t acc = 0;
+            for (size_t b = 0; b < k_type; ++b) {
+                off[c * k_type + b] = acc;
+                acc += (uint32_t)n_r[c * K + b_lo + b];
+            }
+        }
+        SCHK(dalloc(&d_block_off, off.size()));
+        SCHK(hipMemcpy(d_block_off, off.data(), sizeof(uint32_t) * off.size(), hipMemcpyHostToDevice));
+        sp.block_off = d_block_off;
+    }
     SCHK(launch_split_rank(sp, h->stream));
 
     // mt19937-compat: the cuts come from std::shuffle on the chain's engine (:541-543), as bits at (block offset + rank)
@@ -1758,6 +1798,11 @@ int run_split(bisbm_engine* h, int type, int nm) {
 
     // trials in batches of at most ~256 MB of counts
     const size_t per_trial = C * k_type * k_oth * sizeof(int32_t);
+    if (per_trial > ((size_t)2 << 30)) {
+        cleanup();
+        return fail(h, BISBM_ERR_UNSUPPORTED, "agg_split: the edge counts of one trial take %.1f GB (%zu chains x %zu x %zu blocks); use fewer chains",
+                    (double)per_trial / 1e9, C, k_type, k_oth);
+    }
     const size_t batch = std::max<size_t>(1, std::min<size_t>((size_t)nm, ((size_t)256 << 20) / std::max<size_t>(per_trial, 1)));
     SCHK(dalloc(&d_out_k, C * batch * k_type * k_oth));
     SCHK(dalloc(&d_out_deg, C * batch * k_type));
@@ -1775,6 +1820,10 @@ int run_split(bisbm_engine* h, int type, int nm) {
         const size_t nt = std::min(batch, (size_t)nm - t0);
         sp.trial0 = (uint32_t)t0;
         sp.n_trials = (uint32_t)nt;
+        if (h->wide) {  // (counted with global atomics)
+            SCHK(hipMemsetAsync(d_out_k, 0, sizeof(int32_t) * C * nt * k_type * k_oth, h->stream));
+            SCHK(hipMemsetAsync(d_out_deg, 0, sizeof(int32_t) * C * nt * k_type, h->stream));
+        }
         SCHK(launch_split_eval(sp, h->stream));
         SCHK(hipStreamSynchronize(h->stream));
         SCHK(hipMemcpy(out_k.data(), d_out_k, sizeof(int32_t) * C * nt * k_type * k_oth, hipMemcpyDeviceToHost));

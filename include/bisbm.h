@@ -71,8 +71,8 @@ typedef enum bisbm_schedule {
  * No more blocks than nodes of a type, and a shape bisbm_check_shape accepts.  With ka + kb > 256 (the reference's --merge driver starts from one
  * block per node, mcmc_main.cc:350-353) the handle runs in WIDE MODE: two-byte labels, the block matrix read and updated in
  * HBM, the generic kernel (slow per step; meant for the greedy sweeps between merge stages); bisbm_agg_merge switches it to
- * byte labels and the ordinary kernels as soon as it leaves ka + kb <= 256.  Splits are refused (BISBM_ERR_UNSUPPORTED)
- * while wide. */
+ * byte labels and the ordinary kernels as soon as it leaves ka + kb <= 256; a split (negative diff) that takes a handle past
+ * 256 blocks switches it to wide mode, and splits are served while wide. */
 int bisbm_create(bisbm_handle *out, uint64_t n, uint64_t na, uint64_t nb, const uint64_t *rowptr,
                  const uint32_t *col, uint32_t ka, uint32_t kb, double epsilon, uint32_t n_chains,
                  uint32_t first_chain_id, int device, int rng_mode, uint64_t seed,

@@ -1019,9 +1019,9 @@ def test_cli_merge_nature_on_1000_nodes():
 
 
 def test_wide_mode_merges_down_into_byte_labels():
-    """API level, both RNG modes, several chains: 150 + 150 blocks (wide) merged to 140 + 140 (still wide), swept, merged to
-    100 + 100 (byte labels from here), swept -- state equal to the oracle's after every call; the marginal histogram is served there too,
-    splits are refused with a message."""
+    """API level, both RNG modes, several chains: 150 + 150 blocks (wide) split to 151 + 151 (agg_split while wide, round 3),
+    merged to 141 + 141 (still wide), swept, merged to 101 + 101 (byte labels from here), swept -- state equal to the oracle's after
+    every call; the marginal histogram is served there too."""
     rowptr, col = cases.random_graph(91, 300, 300, 5000, 150, 150)
     na = nb = 300
     n = na + nb
@@ -1040,11 +1040,14 @@ def test_wide_mode_merges_down_into_byte_labels():
                 o.seed_philox(5, c)
             o.shuffle_bisbm()
             os_.append(o)
-        with pytest.raises(RuntimeError, match="256 blocks"):
-            g.agg_merge(-1, 0, 5)
+        g.agg_merge(-1, -1, 5)  # a split of each type above 256 blocks (blockmodel.cc:110-117 -> agg_split :505-565)
+        for c, o in enumerate(os_):
+            assert o.agg_merge(-1, -1, 5) == 0
+            assert_state_equal(g, o, c)
+        assert (g.KA, g.KB) == (151, 151)
         g.marginals_reset()  # (the histogram is counted in HBM when a row of counters per thread no longer fits the LDS)
         g.marginals_accumulate(None)
-        want = B.distributed.numpy_marginals(np.stack([o.memberships() for o in os_]), na, 150, 150)
+        want = B.distributed.numpy_marginals(np.stack([o.memberships() for o in os_]), na, 151, 151)
         assert (g.marginals_get() == want).all()
         for (da, db), sched in (((10, 10), ("constant", [1.0])), ((40, 40), ("abrupt_cool", [0.0]))):
             g.agg_merge(da, db, 10)
@@ -1055,7 +1058,7 @@ def test_wide_mode_merges_down_into_byte_labels():
                 ro = o.anneal(sched[0], sched[1], 2 * n, BIG)
                 assert rg[c] == ro
                 assert_state_equal(g, o, c)
-        assert (g.KA, g.KB) == (100, 100)
+        assert (g.KA, g.KB) == (101, 101)
         ent = g.entropy()
         for c, o in enumerate(os_):
             assert abs(ent[c] - o.entropy()) <= 1e-9 * abs(o.entropy())
@@ -1231,3 +1234,46 @@ def test_full_size_properties():
         assert (np.bincount(lab, minlength=ka + kb) == n_r).all()
     ms, updates = g.last_sweep_timing()
     assert updates == chains * (na + nb) and ms > 0
+
+@pytest.mark.parametrize("mode", ["philox", "compat"])
+def test_splits_cross_256_blocks_and_come_back(mode):
+    """127 + 128 blocks (byte labels), three splits: 128 + 128 = 256 (still bytes), 128 + 129 = 257 (the labels become two bytes:
+    wide mode), 129 + 129; a sweep in wide mode; a merge back to 120 + 120 (bytes again); a sweep.  Equal to the oracle after
+    every call, in every chain."""
+    rowptr, col = cases.random_graph(17, 400, 400, 6000, 127, 128)
+    na = nb = 400
+    n = na + nb
+    labels = O.contiguous_labels(na, nb, 127, 128)
+    chains = 3
+    g = gpu_model(rowptr, col, na, nb, 127, 128, 1.0, labels, n_chains=chains, rng=mode, seed=21, gen_seed=22)
+    g.shuffle_bisbm()
+    os_ = []
+    for c in range(chains):
+        o = O.OracleModel(rowptr, col, na, nb, 127, 128, 1.0, labels)
+        if mode == "compat":
+            o.seed_compat(21 + c, 22 + c)
+        else:
+            o.seed_philox(21, c)
+        o.shuffle_bisbm()
+        os_.append(o)
+    mh = B.MetropolisHasting()
+    for da, db, shape in ((-1, 0, (128, 128)), (0, -1, (128, 129)), (-1, 0, (129, 129))):
+        g.agg_merge(da, db, 6)
+        assert (g.KA, g.KB) == shape
+        for c, o in enumerate(os_):
+            assert o.agg_merge(da, db, 6) == 0
+            assert_state_equal(g, o, c)
+    for sched, kw, (da, db) in (("constant", [1.0], (0, 0)), ("abrupt_cool", [0.0], (9, 9))):
+        if da:
+            g.agg_merge(da, db, 10)
+            for o in os_:
+                assert o.agg_merge(da, db, 10) == 0
+        rg = mh.anneal(g, sched, kw, 2 * n, BIG)
+        for c, o in enumerate(os_):
+            assert o.anneal(sched, kw, 2 * n, BIG) == rg[c]
+            assert_state_equal(g, o, c)
+    assert (g.KA, g.KB) == (120, 120)
+    ent = g.entropy()
+    for c, o in enumerate(os_):
+        assert abs(ent[c] - o.entropy()) <= 1e-9 * abs(o.entropy())
+
