@@ -900,8 +900,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const int qn = mm + __mul24(ideg, dsgn_l);        // m0r, m0s, m0r - deg, m0s + deg
                     const uint32_t tail_idx = (uint32_t)((qn ^ ((qn ^ ee) & eta_mask_l)) + toff_l);
                     const int qk = nn + dq_l;
-                    const double tail_lg = tab_at(tab.lg, tail_idx);
                     const double logn = tab_at(tab.logtab, (uint32_t)qn);
+                    const double tail_lg = tab_at(tab.lg, tail_idx);
                     const double L2 = tab_at(tab.lg, (uint32_t)(m_st + 1));
                     const double L4 = tab_at(tab.lg, (uint32_t)(m_st + 1) + kk);
                     FSTAMP_STEP(3);

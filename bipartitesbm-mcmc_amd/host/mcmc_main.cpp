@@ -19,6 +19,8 @@
 #include <memory>
 #include <set>
 #include <string>
+#include <thread>
+#include <atomic>
 #include <vector>
 
 #include "bisbm.hpp"
@@ -484,41 +486,71 @@ int main(int argc, char const* argv[]) {
             if (nature && opt.n_chains > 1) {
                 // agg_merge(engine, diff, nm) lets every run end with its own (Ka,Kb) (blockmodel.cc:208-271), and in this
                 // driver every run also has its own stage sizes (ceil of ITS block count) and its own last stage: --nature
-                // --chains N therefore runs the N chains one after the other, each in a handle of its own with its global
-                // chain id (same streams as in one handle), and prints the best.  (One handle does serve chains of
+                // --chains N therefore runs every chain in a handle of its own with its global chain id (same streams as in
+                // one handle), and prints the best.  (One handle does serve chains of
                 // different shapes -- bisbm_agg_merge_total -- but applies one diff to all of them per call.)
+                // The runs are independent handles: up to eight of them are in flight at a time, each on a host thread of its own
+                // (its handle has its own stream; with --devices they take turns over the listed devices).
+                if (cooling_schedule != "abrupt_cool" &&  // (the reference notices inside its first merge stage, :370-376)
+                    std::min(NA, NB) >= (size_t)std::ceil(std::sqrt(2. * (double)(adj_list.col.size() / 2)) / 2)) {
+                    std::cerr << "Only abrupt cooling annealing is supported.";
+                    return 1;
+                }
+                struct run_result {
+                    double dl = std::numeric_limits<double>::infinity();
+                    uint_vec_t labels;
+                    size_t ka = 0, kb = 0;
+                    std::string error;
+                };
+                std::vector<run_result> runs(opt.n_chains);
+                auto run_one = [&](uint32_t c) {
+                    try {
+                        engine_options one = opt;
+                        one.n_chains = 1;
+                        one.first_chain_id = opt.first_chain_id + c;
+                        if (!opt.devices.empty()) one.device = opt.devices[c % opt.devices.size()];  // (--devices: the runs take turns)
+                        one.devices.clear();
+                        blockmodel_t blockmodel(memberships_init, types_init, NA + NB, NA, NB, epsilon, &adj_list, one);
+                        blockmodel.init_bisbm();
+                        metropolis_hasting algorithm;
+                        size_t tKA = NA, tKB = NB, tGroups = NA + NB;
+                        const size_t ceiling = (size_t)std::ceil(std::sqrt(2. * blockmodel.get_num_edges()) / 2);
+                        while (tKA >= ceiling && tKB >= ceiling) {  // :357-377
+                            blockmodel.agg_merge((int)std::ceil(tGroups * (sigma - 1) / sigma), 10);
+                            tKA = blockmodel.get_KA();
+                            tKB = blockmodel.get_KB();
+                            tGroups = tKA + tKB;
+                            algorithm.anneal(blockmodel, &abrupt_cool_schedule, agg_merge_kwargs, (NA + NB) * 1, steps_await);
+                        }
+                        algorithm.anneal(blockmodel, &abrupt_cool_schedule, kwargs, sampling_steps, steps_await);  // :398
+                        runs[c].dl = blockmodel.entropy_all()[0];
+                        runs[c].labels = *blockmodel.get_memberships(0);
+                        runs[c].ka = blockmodel.get_KA();
+                        runs[c].kb = blockmodel.get_KB();
+                    } catch (const std::exception& e) {
+                        runs[c].error = e.what();
+                    }
+                };
+                {
+                    const uint32_t width = std::min<uint32_t>(opt.n_chains, 8u);
+                    std::vector<std::thread> pool;
+                    std::atomic<uint32_t> next{0};
+                    for (uint32_t t = 0; t < width; ++t)
+                        pool.emplace_back([&] {
+                            for (uint32_t c = next++; c < opt.n_chains; c = next++) run_one(c);
+                        });
+                    for (auto& t : pool) t.join();
+                }
                 double best_dl = std::numeric_limits<double>::infinity();
                 uint_vec_t best_labels;
                 size_t best_ka = 0, best_kb = 0, best_chain = 0;
                 for (uint32_t c = 0; c < opt.n_chains; ++c) {
-                    engine_options one = opt;
-                    one.n_chains = 1;
-                    one.first_chain_id = opt.first_chain_id + c;
-                    if (!opt.devices.empty()) one.device = opt.devices[c % opt.devices.size()];  // (--devices: the runs take turns)
-                    one.devices.clear();
-                    blockmodel_t blockmodel(memberships_init, types_init, NA + NB, NA, NB, epsilon, &adj_list, one);
-                    blockmodel.init_bisbm();
-                    metropolis_hasting algorithm;
-                    size_t tKA = NA, tKB = NB, tGroups = NA + NB;
-                    const size_t ceiling = (size_t)std::ceil(std::sqrt(2. * blockmodel.get_num_edges()) / 2);
-                    while (tKA >= ceiling && tKB >= ceiling) {  // :357-377
-                        blockmodel.agg_merge((int)std::ceil(tGroups * (sigma - 1) / sigma), 10);
-                        tKA = blockmodel.get_KA();
-                        tKB = blockmodel.get_KB();
-                        tGroups = tKA + tKB;
-                        if (cooling_schedule != "abrupt_cool") {
-                            std::cerr << "Only abrupt cooling annealing is supported.";
-                            return 1;
-                        }
-                        algorithm.anneal(blockmodel, &abrupt_cool_schedule, agg_merge_kwargs, (NA + NB) * 1, steps_await);
-                    }
-                    algorithm.anneal(blockmodel, &abrupt_cool_schedule, kwargs, sampling_steps, steps_await);  // :398
-                    const double dl = blockmodel.entropy_all()[0];
-                    if (dl < best_dl) {
-                        best_dl = dl;
-                        best_labels = *blockmodel.get_memberships(0);
-                        best_ka = blockmodel.get_KA();
-                        best_kb = blockmodel.get_KB();
+                    if (!runs[c].error.empty()) throw std::runtime_error(runs[c].error);
+                    if (runs[c].dl < best_dl) {  // (the first of equals, as when the runs went one after the other)
+                        best_dl = runs[c].dl;
+                        best_labels = runs[c].labels;
+                        best_ka = runs[c].ka;
+                        best_kb = runs[c].kb;
                         best_chain = c;
                     }
                 }
