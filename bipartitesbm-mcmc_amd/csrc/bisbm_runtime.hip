@@ -1957,7 +1957,8 @@ int run_merges(bisbm_engine* h, int which, int diff_a, int diff_b, int nm, std::
         }                                                                                              \
     } while (0)
     MCHK(hipMemcpy(d_map, ident.data(), ident.size(), hipMemcpyHostToDevice));
-    MCHK(hipMemset(d_first, 0xff, sizeof(uint32_t) * C * L));
+    // (on the handle's stream: it is a non-blocking stream, which a null-stream memset is not ordered with)
+    MCHK(hipMemsetAsync(d_first, 0xff, sizeof(uint32_t) * C * L, h->stream));
     MCHK(launch_merge_first(h->d_labels, h->wide, h->label_stride, (uint32_t)h->n, h->n_chains, (uint32_t)L, d_map, d_first, h->stream));
     MCHK(hipStreamSynchronize(h->stream));
     std::vector<uint32_t> first(C * L);
