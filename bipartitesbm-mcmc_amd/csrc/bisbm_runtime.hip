@@ -886,7 +886,8 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     // where the chain is, so it is MEASURED: every launch is timed, the depth with the best updates per ms so far runs, and
     // every sixteenth launch tries a neighbouring depth again (a chain leaves its burn-in).  The chain is the same chain whatever
     // runs (same Philox counters, bit-equal results).
-    const uint32_t max_depth = (!fast || p.pair_steps < 2u || h->ka > 16 || h->kb > 16) ? 0u
+    // (depth 1 = two steps per pass, 2 = four -- in 16-lane rows, two blocks per lane above 16 blocks of a type --, 3 = eight)
+    const uint32_t max_depth = (!fast || p.pair_steps < 2u || h->ka > 32 || h->kb > 32) ? 0u
                                : std::min<uint32_t>(p.pair_steps, (h->ka <= 8 && h->kb <= 8) ? 3u : 2u);
     // ("no early stop in reach": at T >= 1 the count u of metropolis_hasting.cc:85-98 stays 0, so the test `u >= steps_await`
     // after a sweep fires exactly when steps_await == 0 -- then the call ends after its FIRST sweep with rate accepted / N

@@ -116,8 +116,9 @@ constexpr uint32_t kRowCap = 255;     // longest row the feeder walks (a k_v cou
 // p.eta_lo_a / p.eta_lo_b on (chosen by the host to hold most nodes), swapped at the phase change -- steps of nodes whose degree
 // lies outside take the general path, which reads and writes those entries in HBM.  CT: constant schedule.  K32: both block counts <= 32 (five-level scans and sums).  K16 (with K32): both
 // block counts <= 16: four steps per pass in the four 16-lane rows of the wave (step_quad).  K8 (with K16): both <= 8: eight
-// steps per pass in groups of eight lanes (step_oct).
-template <bool EL, bool CT, bool K32, bool K16, bool K8>
+// steps per pass in groups of eight lanes (step_oct).  Q32 (with K32, without K16): four steps per pass with up to 32 blocks
+// of a type, two blocks per lane (step_quad32) -- the kernel of a launch whose pass depth the host set to four.
+template <bool EL, bool CT, bool K32, bool K16, bool K8, bool Q32>
 __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p) {
     extern __shared__ __align__(16) uint32_t lds32[];
     const uint32_t chain = blockIdx.x;
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     // two steps per pass with more than 32 blocks of a type (step_pair64: two leaves per lane)
     const bool pair64_mode = (uint32_t)__builtin_amdgcn_readfirstlane((!K32 && (!CT || T_const > 0.) && p.pair_steps != 0) ? 1 : 0) != 0u;
     const bool quad_mode = (uint32_t)__builtin_amdgcn_readfirstlane((K16 && !K8 && (!CT || T_const > 0.) && p.pair_steps > 1u) ? 1 : 0) != 0u;
+    const bool quad32_mode = (uint32_t)__builtin_amdgcn_readfirstlane((Q32 && (!CT || T_const > 0.) && p.pair_steps > 1u) ? 1 : 0) != 0u;
     const bool oct_mode = (uint32_t)__builtin_amdgcn_readfirstlane((K8 && (!CT || T_const > 0.) && p.pair_steps > 2u) ? 1 : 0) != 0u;
     const uint32_t track_min =
         (uint32_t)__builtin_amdgcn_readfirstlane(((!CT || T_const < 1.) && p.steps_await <= p.call_duration) ? 1 : 0);
@@ -325,15 +327,22 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
             auto inv_oth_of_lane = [&]() -> double { return K32 ? inv_blk : (lane < 32u ? inv_lo : inv_hi); };
             // the scalar terms of dS sit in leaves 0..7 (lgamma) / 0..3 (log_q) of a step's sum: lane pattern by the lane's
             // position in its half / row / group (K > 32: in its half, for step_pair64)
-            const uint32_t ls = K32 ? lb : lh;
+            // step_quad32 (17..32 blocks of a type, four steps per pass): lane l of a 16-lane row holds the opposite-type blocks
+            // l and l + 16 (two leaves per lane) and, for the inverse CDF, the own-type blocks l and l + 16
+            const uint32_t l16 = lane & 15u;
+            const double invq_lo = __hiloint2double(__builtin_amdgcn_ds_bpermute((int)(l16 << 2), __double2hiint(inv_blk)),
+                                                    __builtin_amdgcn_ds_bpermute((int)(l16 << 2), __double2loint(inv_blk)));
+            const double invq_hi = __hiloint2double(__builtin_amdgcn_ds_bpermute((int)((l16 + 16u) << 2), __double2hiint(inv_blk)),
+                                                    __builtin_amdgcn_ds_bpermute((int)((l16 + 16u) << 2), __double2loint(inv_blk)));
+            const uint32_t ls = Q32 ? l16 : (K32 ? lb : lh);
             const double sign_tail = ls >= 8 ? 0. : ((ls < 2 || ls >= 6) ? -1. : 1.);
             const double sign_q = ls >= 4 ? 0. : (ls < 2 ? -1. : 1.);
             // the one-step evaluations (step_general, step) sum lanes 0..31 or 0..63 as ONE step: only its first row carries
             // the scalar terms (with several copies per wave -- K <= 16, or the two halves of the K > 32 variant -- the other
             // copies would add them again).  K <= 16: registers of their own; K > 32: selected at the use (registers are
             // scarce there); K <= 32: the same registers as sign_tail / sign_q.
-            const double sign_tail1_r = K16 ? (lane < 8u ? sign_tail : 0.) : sign_tail;
-            const double sign_q1_r = K16 ? (lane < 8u ? sign_q : 0.) : sign_q;
+            const double sign_tail1_r = (K16 || Q32) ? (lane < 8u ? sign_tail : 0.) : sign_tail;
+            const double sign_q1_r = (K16 || Q32) ? (lane < 8u ? sign_q : 0.) : sign_q;
             auto sign_tail1_of = [&]() -> double { return K32 ? sign_tail1_r : (lane < 32u ? sign_tail : 0.); };
             auto sign_q1_of = [&]() -> double { return K32 ? sign_q1_r : (lane < 32u ? sign_q : 0.); };
             const int eoff_l = (lane & 7u) < 6 ? 1 : ((lane & 1u) ? 2 : 0);       // eta_r+1, eta_s+1, eta_r, eta_s+2
@@ -349,6 +358,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
             const unsigned long long lanes_koth = __builtin_amdgcn_ballot_w64(lb < k_oth);  // both halves in the K <= 32 variants
             const unsigned long long lanes_koth64_lo = __builtin_amdgcn_ballot_w64((lane & 31u) < k_oth);       // step_pair64: the lane's
             const unsigned long long lanes_koth64_hi = __builtin_amdgcn_ballot_w64((lane & 31u) + 32u < k_oth);  // two opposite-type blocks
+            const unsigned long long lanes_koth32_lo = __builtin_amdgcn_ballot_w64((lane & 15u) < k_oth);        // step_quad32: the lane's
+            const unsigned long long lanes_koth32_hi = __builtin_amdgcn_ballot_w64((lane & 15u) + 16u < k_oth);  // two opposite-type blocks
             const uint32_t node_other0 = TB ? 0u : na;  // some node of the opposite type: what idle slots of the walk load
 
             // The proposal's random part (blockmodel.cc:619-628), worked out for all 64 steps of a chunk at once (lane = step) by
@@ -663,6 +674,44 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 // ---- the 64 steps.  Hot path: 1 <= deg <= 255, target drawn from column m[.][t], T > 0 ----
                 const uint32_t last_own = k_own - 1;
                 const double invT_const = 1.0 / T_const;
+                // log_q of the hot steps: four (n, k) pairs per step, one per lane (mod 4).  Above the table, tier u = k / sqrt(n) > 24
+                // (k^2 > 576 n: blocks of more than ~12 000 nodes at mean degree 20) is log_q_closed, 13 <= u <= 24 log_q_closed2,
+                // 8 <= u < 13 log_q_mid (bisbm_device.hpp): the functions and the exact tier tests of log_q_approx<true>, on pinned
+                // constants.  The tier is the LANE's -- a pass holds the arguments of up to eight steps, and a value that depended on
+                // which tiers the other lanes are in would depend on the depth of the pass -- but only the tiers some lane needs are
+                // evaluated (wave-uniform branches): all lanes far out, the common case on large blocks, is one straight line.
+                // Anything else (arguments inside and outside the table in one pass, u < 8) goes through log_q<true> itself.
+                // mid: whether the 8 <= u < 13 tier is inlined here (not where registers are scarcest).
+                auto hot_log_q = [&](auto mid_tag, int qn, int qk, double logn) -> double {
+                    constexpr bool MID = decltype(mid_tag)::value;
+                    const int qk2 = qk < qn ? qk : qn;
+                    const double nd = (double)qn, kd = (double)qk2;
+                    const double k2 = kd * kd;
+                    const bool big = qn > kQNmax;
+                    const bool direct = big && k2 > c_576 * nd;
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!direct) == 0, 1)) {
+                        double sq, rr;
+                        sqrt_rsqrt(nd, sq, rr);
+                        return log_q_closed(kd, sq, rr, logn, lqc);
+                    }
+                    if (__builtin_amdgcn_ballot_w64(big) == 0) return log_q_table(tab, qn, qk2);  // small graphs (int_part.hh:27-37)
+                    const bool ge13 = big && k2 >= c_169 * nd;
+                    const bool ge8 = big && k2 >= ldexp(nd, 6);
+                    if (__builtin_amdgcn_ballot_w64(MID ? !ge8 : !ge13) != 0) return log_q<true>(tab, qn, qk, logn);
+                    double sq, rr;
+                    sqrt_rsqrt(nd, sq, rr);
+                    double lq = 0.;
+                    if (__builtin_amdgcn_ballot_w64(ge13 && !direct) != 0) lq = log_q_closed2(kd, sq, rr, logn, lqc);
+                    if (MID && __builtin_amdgcn_ballot_w64(!ge13) != 0) {
+                        const double lq_mid = log_q_mid(kd, sq, rr, logn, lqc);
+                        lq = ge13 ? lq : lq_mid;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(direct) != 0) {
+                        const double lq_far = log_q_closed(kd, sq, rr, logn, lqc);
+                        lq = direct ? lq_far : lq;
+                    }
+                    return lq;
+                };
                 // One step.  Early returns only (each is a jump to the loop latch); the rare cases leave through
                 // step_general at the top, before anything is computed.  A rejected step changes nothing, not even a
                 // register, unless the early-stop bookkeeping is on (T < 1).
@@ -749,34 +798,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     // bisbm_device.hpp on pinned constants and tier 8 <= u <= 24 the converged evaluation, the same
                     // functions and the same exact tier tests as log_q_approx<true>; anything else goes through
                     // log_q<true> itself.
-                    double lq;
-                    {
-                        const int qk2 = qk < qn ? qk : qn;
-                        const double nd = (double)qn, kd = (double)qk2;
-                        const double k2 = kd * kd;
-                        const bool direct = qn > kQNmax && k2 > c_576 * nd;
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!direct) == 0, 1)) {  // (lanes repeat mod 4)
-                            double sq, rr;
-                            sqrt_rsqrt(nd, sq, rr);
-                            lq = log_q_closed(kd, sq, rr, logn, lqc);
-                        } else if (__builtin_amdgcn_ballot_w64(qn > kQNmax) == 0) {
-                            lq = log_q_table(tab, qn, qk2);  // small graphs: every argument inside the table
-                        } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= c_169 * nd)) == 0) {
-                            double sq, rr;  // u >= 13 everywhere: second-order closed form (also right for u > 24)
-                            sqrt_rsqrt(nd, sq, rr);
-                            lq = log_q_closed2(kd, sq, rr, logn, lqc);
-                        } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= ldexp(nd, 6))) == 0) {
-                            // blocks of a thousand to a few thousand nodes (8 <= u < 13 for some of the four arguments):
-                            // the converged tier, and the closed form where it applies -- both straight-line code
-                            double sq, rr;
-                            sqrt_rsqrt(nd, sq, rr);
-                            const double lq_mid = log_q_mid(kd, sq, rr, logn, lqc);
-                            const double lq_far = log_q_closed(kd, sq, rr, logn, lqc);
-                            lq = direct ? lq_far : lq_mid;
-                        } else {
-                            lq = log_q<true>(tab, qn, qk, logn);
-                        }
-                    }
+                    const double lq = hot_log_q(std::true_type{}, qn, qk, logn);
                     FSTAMP_STEP(5);
                     double d = (L1 + L2) - (L3 + L4);
                     d = d + tail_lg * sign_tail1_of();  // scalar terms folded into leaves 0..7 / 0..3, see step_general
@@ -933,34 +955,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     double accu0, accu1;  // lanes 16..31: step q, lanes 48..63: step q + 1
                     butterfly_accu_rows32(a0, a1, accu0, accu1);
                     FSTAMP_STEP(4);
-                    double lq;
-                    {
-                        const int qk2 = qk < qn ? qk : qn;
-                        const double nd = (double)qn, kd = (double)qk2;
-                        const double k2 = kd * kd;
-                        const bool direct = qn > kQNmax && k2 > c_576 * nd;
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!direct) == 0, 1)) {
-                            double sq, rr;
-                            sqrt_rsqrt(nd, sq, rr);
-                            lq = log_q_closed(kd, sq, rr, logn, lqc);
-                        } else if (__builtin_amdgcn_ballot_w64(qn > kQNmax) == 0) {
-                            lq = log_q_table(tab, qn, qk2);  // small graphs: every argument inside the table (int_part.hh:27-37)
-                        } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= c_169 * nd)) == 0) {
-                            // u >= 13 in every lane (blocks of a few thousand nodes): the second-order closed form, which
-                            // also serves the lanes with u > 24
-                            double sq, rr;
-                            sqrt_rsqrt(nd, sq, rr);
-                            lq = log_q_closed2(kd, sq, rr, logn, lqc);
-                        } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= ldexp(nd, 6))) == 0) {
-                            double sq, rr;
-                            sqrt_rsqrt(nd, sq, rr);
-                            const double lq_mid = log_q_mid(kd, sq, rr, logn, lqc);
-                            const double lq_far = log_q_closed(kd, sq, rr, logn, lqc);
-                            lq = direct ? lq_far : lq_mid;
-                        } else {
-                            lq = log_q<true>(tab, qn, qk, logn);
-                        }
-                    }
+                    const double lq = hot_log_q(std::true_type{}, qn, qk, logn);
                     FSTAMP_STEP(5);
                     double d = (L1 + L2) - (L3 + L4);
                     d = d + tail_lg * sign_tail;
@@ -1120,26 +1115,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double a1 = k0 * (m_rt0 - k0 + eps) * inv_lo + k1 * (m_rt1 - k1 + eps) * inv_hi;
                     double accu0, accu1;  // lanes 16..31: step q, lanes 48..63: step q + 1
                     butterfly_accu_rows32(a0, a1, accu0, accu1);
-                    double lq;
-                    {
-                        const int qk2 = qk < qn ? qk : qn;
-                        const double nd = (double)qn, kd = (double)qk2;
-                        const double k2 = kd * kd;
-                        const bool direct = qn > kQNmax && k2 > c_576 * nd;
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!direct) == 0, 1)) {
-                            double sq, rr;
-                            sqrt_rsqrt(nd, sq, rr);
-                            lq = log_q_closed(kd, sq, rr, logn, lqc);
-                        } else if (__builtin_amdgcn_ballot_w64(qn > kQNmax) == 0) {
-                            lq = log_q_table(tab, qn, qk2);
-                        } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= c_169 * nd)) == 0) {
-                            double sq, rr;
-                            sqrt_rsqrt(nd, sq, rr);
-                            lq = log_q_closed2(kd, sq, rr, logn, lqc);
-                        } else {  // (the converged tier for 8 <= u < 13 is not inlined here: registers; the out-of-line evaluation holds it)
-                            lq = log_q<true>(tab, qn, qk, logn);
-                        }
-                    }
+                    const double lq = hot_log_q(std::false_type{}, qn, qk, logn);
                     double d = (L1_0 + L2_0) - (L3_0 + L4_0);
                     d = d + tail_lg * sign_tail;  // the scalar terms sit in leaves 0..7 / 0..3: the lane's lower leaf
                     d = d + lq * sign_q;
@@ -1280,32 +1256,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double a1 = k * (m_rt - k + eps) * inv_blk;
                     const double accu0 = butterfly_rows16(a0);  // every lane of a row: the row's sum
                     const double accu1 = butterfly_rows16(a1);
-                    double lq;
-                    {
-                        const int qk2 = qk < qn ? qk : qn;
-                        const double nd = (double)qn, kd = (double)qk2;
-                        const double k2 = kd * kd;
-                        const bool direct = qn > kQNmax && k2 > c_576 * nd;
-                        if (__builtin_amdgcn_ballot_w64(qn > kQNmax) == 0) {
-                            lq = log_q_table(tab, qn, qk2);  // small graphs: every argument inside the table (int_part.hh:27-37)
-                        } else if (__builtin_amdgcn_ballot_w64(!direct) == 0) {
-                            double sq, rr;
-                            sqrt_rsqrt(nd, sq, rr);
-                            lq = log_q_closed(kd, sq, rr, logn, lqc);
-                        } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= c_169 * nd)) == 0) {
-                            double sq, rr;
-                            sqrt_rsqrt(nd, sq, rr);
-                            lq = log_q_closed2(kd, sq, rr, logn, lqc);
-                        } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= ldexp(nd, 6))) == 0) {
-                            double sq, rr;
-                            sqrt_rsqrt(nd, sq, rr);
-                            const double lq_mid = log_q_mid(kd, sq, rr, logn, lqc);
-                            const double lq_far = log_q_closed(kd, sq, rr, logn, lqc);
-                            lq = direct ? lq_far : lq_mid;
-                        } else {
-                            lq = log_q<true>(tab, qn, qk, logn);
-                        }
-                    }
+                    const double lq = hot_log_q(std::true_type{}, qn, qk, logn);
                     double d = (L1 + L2) - (L3 + L4);
                     d = d + tail_lg * sign_tail;
                     d = d + lq * sign_q;
@@ -1392,6 +1343,193 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     }
                     acc_l0 += (unsigned long long)acc_chunk;
                 };
+                // ---- four steps per pass with 17..32 blocks of a type (the Q32 variant) ----
+                // step_quad with TWO leaves per lane, the way step_pair64 extends step_pair: lane l of row g (step q + g) holds the
+                // opposite-type blocks l and l + 16 -- their k, their entries of rows r and s, their table gathers, their leaves of the
+                // three sums -- and, for the inverse CDF, entries l and l + 16 of column t.  The summation trees are the 64-leaf ones
+                // (bisbm_device.hpp): the Hastings sums have level 16 second, so the lane adds its two leaves first; dS has it last,
+                // so its two 16-leaf halves are summed separately and added at the end.  m_r / n_r sit one block per lane (two copies,
+                // lanes 0..31 and 32..63) and are read by lane index.  Stand rule, verdicts and writes are step_quad's.
+                auto step_quad32 = [&](auto tm, uint32_t q, uint32_t nst) -> uint32_t {  // nst: steps of this pass that exist (1..4)
+                    constexpr bool TM = decltype(tm)::value;
+                    const uint32_t qs = q + min(row, nst - 1u);  // (rows past nst repeat the last step; their results are ignored)
+                    const int sel = (int)(qs << 2);
+                    const uint32_t prop = prop_of(qs);
+                    const uint32_t pack = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)pack_l);
+                    const double u_acc = u_acc_of(qs);
+                    const uint32_t deg = pack & 255u, r_loc = (pack >> 8) & 63u, t_loc = pack >> 16;
+                    const int k0 = (int)hist8_cur[qs * kHistStride + l16], k1 = (int)hist8_cur[qs * kHistStride + l16 + 16u];
+                    const uint32_t a_rt0 = mq_at(r_loc, l16), a_rt1 = mq_at(r_loc, l16 + 16u);
+                    const int32_t m_rt_raw0 = mq[a_rt0], m_rt_raw1 = mq[a_rt1];
+                    const int w0 = mq[mq_at(l16, t_loc)], w1 = mq[mq_at(l16 + 16u, t_loc)];
+                    const int nn_r = __builtin_amdgcn_ds_bpermute((int)(r_loc << 2), nr_own);
+                    const int32_t kmask0 = (0 - k0) >> 31, kmask1 = (0 - k1) >> 31;
+                    const int32_t m_rt0 = m_rt_raw0 & kmask0, m_rt1 = m_rt_raw1 & kmask1;
+                    const uint32_t kk0 = (uint32_t)k0, kk1 = (uint32_t)k1;
+                    const double L1_0 = tab_at(tab.lg, (uint32_t)(m_rt0 + 1)), L3_0 = tab_at(tab.lg, (uint32_t)(m_rt0 + 1) - kk0);
+                    const double L1_1 = tab_at(tab.lg, (uint32_t)(m_rt1 + 1)), L3_1 = tab_at(tab.lg, (uint32_t)(m_rt1 + 1) - kk1);
+                    __asm__ volatile("" ::: "memory");
+                    // inverse CDF per row over 32 own blocks (:627-628): the scan of blocks 0..15, its total, the scan of blocks
+                    // 16..31 on top (garbage past k_own, see step_pair64)
+                    const int scan0 = row_inclusive_scan16(w0);
+                    int tot = w0;  // (the row's total by four xor levels: every lane gets it without an LDS round trip)
+                    tot += __builtin_amdgcn_update_dpp(0, tot, kDppXor1, 0xF, 0xF, false);
+                    tot += __builtin_amdgcn_update_dpp(0, tot, kDppXor2, 0xF, 0xF, false);
+                    tot += __builtin_amdgcn_update_dpp(0, tot, kDppHalfMirror, 0xF, 0xF, false);
+                    tot += __builtin_amdgcn_update_dpp(0, tot, kDppMirror, 0xF, 0xF, false);
+                    const int scan1 = row_inclusive_scan16(w1) + tot;
+                    const unsigned long long hit0 = __builtin_amdgcn_ballot_w64((uint32_t)scan0 > prop);
+                    const unsigned long long hit1 = __builtin_amdgcn_ballot_w64((uint32_t)scan1 > prop);
+                    const uint32_t field = ((uint32_t)(hit0 >> (row << 4)) & 0xffffu) | ((uint32_t)(hit1 >> (row << 4)) << 16);
+                    const uint32_t s_loc = min((uint32_t)__builtin_ctz(field | 0x80000000u), last_own);
+                    const bool valid = row < nst;
+                    const bool self = s_loc == r_loc;
+                    const bool live = nn_r != 1;  // (:467-471: a block is never emptied)
+                    const bool warm = CT ? true : (((zeroT_mask >> qs) & 1ull) == 0ull);  // T = 0: r == s is not accepted (:49-50)
+                    constexpr unsigned long long kRowRep = 0x8000800080008000ull;  // one lane per row (its last)
+                    const unsigned long long b_can = __builtin_amdgcn_ballot_w64(valid && live && !self) & kRowRep;
+                    const unsigned long long b_selfok = __builtin_amdgcn_ballot_w64(valid && live && self && warm) & kRowRep;
+                    if (b_can == 0ull) {  // every step of the pass is an r == s (or a vetoed one): nothing changes (:109-112)
+                        acc_chunk += (uint32_t)__builtin_popcountll(b_selfok);
+                        if constexpr (TM)
+                            if (b_selfok != 0ull) new_minimum(q + ((uint32_t)__builtin_ctzll(b_selfok) >> 4));
+                        return nst;
+                    }
+                    const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
+                    const uint32_t a_st0 = mq_at(s_loc, l16), a_st1 = mq_at(s_loc, l16 + 16u);
+                    const int32_t m_st_raw0 = mq[a_st0], m_st_raw1 = mq[a_st1];
+                    const uint32_t e_idx = eta_at(idx_l, deg);
+                    const int ee = (int)eta_l[e_idx];
+                    const int mm = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), mr_own);
+                    const int nn = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), nr_own);
+                    const int32_t m_st0 = m_st_raw0 & kmask0, m_st1 = m_st_raw1 & kmask1;
+                    const int ideg = (int)deg;
+                    const int qn = mm + __mul24(ideg, dsgn_l);        // m0r, m0s, m0r - deg, m0s + deg
+                    const uint32_t tail_idx = (uint32_t)((qn ^ ((qn ^ ee) & eta_mask_l)) + toff_l);
+                    const int qk = nn + dq_l;
+                    const double logn = tab_at(tab.logtab, (uint32_t)qn);
+                    const double tail_lg = tab_at(tab.lg, tail_idx);
+                    const double L2_0 = tab_at(tab.lg, (uint32_t)(m_st0 + 1)), L4_0 = tab_at(tab.lg, (uint32_t)(m_st0 + 1) + kk0);
+                    const double L2_1 = tab_at(tab.lg, (uint32_t)(m_st1 + 1)), L4_1 = tab_at(tab.lg, (uint32_t)(m_st1 + 1) + kk1);
+                    // pairwise: would step i, if it moves its node, touch what step j read?  (lane 4 i + j, any row)
+                    // (worked out while the table gathers are in flight: after they have been issued, see step_pair)
+                    uint32_t clash_bits;
+                    {
+                        uint32_t r_c = r_loc, s_c = s_loc, t_c = t_loc;
+                        __asm__ volatile("" : "+v"(r_c), "+v"(s_c), "+v"(t_c)::"memory");
+                        const int li = (int)(((lane >> 2) & 3u) << 6), lj = (int)((lane & 3u) << 6);  // lane 16 i, lane 16 j
+                        const uint32_t r_i = (uint32_t)__builtin_amdgcn_ds_bpermute(li, (int)r_c);
+                        const uint32_t s_i = (uint32_t)__builtin_amdgcn_ds_bpermute(li, (int)s_c);
+                        const uint32_t r_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)r_c);
+                        const uint32_t s_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)s_c);
+                        const uint32_t t_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)t_c);
+                        const int src = li + (int)((t_j & 15u) << 2);  // k of step i at block t_j: leaf t_j >> 4 of lane t_j & 15 of row i
+                        const uint32_t k_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)kk0);
+                        const uint32_t k_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)kk1);
+                        const uint32_t k_i_tj = k_lo ^ ((k_lo ^ k_hi) & (0u - (t_j >> 4)));
+                        const uint32_t set_i = (1u << r_i) | (1u << s_i), set_j = (1u << r_j) | (1u << s_j);
+                        const uint32_t lo = min(r_i, s_i), hi = max(r_i, s_i);
+                        const uint32_t between = ((1u << hi) - 1u) & ~((2u << lo) - 1u);  // blocks strictly between r_i and s_i
+                        // (bit arithmetic, no short-circuit: a lane-divergent `||` becomes a branch over the execution mask)
+                        const uint32_t in_between = (between >> s_j) & min(k_i_tj, 1u);
+                        clash_bits = (uint32_t)__builtin_amdgcn_ballot_w64(((set_i & set_j) | in_between) != 0u) & 0xffffu;  // bit 4 i + j
+                    }
+                    // the lane's two leaves of each Hastings sum, added first (level 16 of their tree)
+                    const double a0 = k0 * (m_st0 + eps) * invq_lo + k1 * (m_st1 + eps) * invq_hi;
+                    const double a1 = k0 * (m_rt0 - k0 + eps) * invq_lo + k1 * (m_rt1 - k1 + eps) * invq_hi;
+                    const double accu0 = butterfly_rows16(a0);  // every lane of a row: the row's sum
+                    const double accu1 = butterfly_rows16(a1);
+                    const double lq = hot_log_q(std::false_type{}, qn, qk, logn);
+                    double d0 = (L1_0 + L2_0) - (L3_0 + L4_0);
+                    d0 = d0 + tail_lg * sign_tail;  // the scalar terms sit in leaves 0..7 / 0..3: the lane's lower leaf
+                    d0 = d0 + lq * sign_q;
+                    const double d1 = (L1_1 + L2_1) - (L3_1 + L4_1);
+                    const double dS = butterfly_rows16(d1) + butterfly_rows16(d0);  // level 16 of the dS tree comes last
+                    // accept (:47-61), per row
+                    double invT = invT_const;
+                    if (!CT) invT = invT_of(qs);
+                    const double z = -dS * invT;
+                    const double est = accu1 * exp2_filter(z * c_l2e);
+                    const double lhs = u_acc * accu0;
+                    unsigned long long b_acc = __builtin_amdgcn_ballot_w64(warm ? lhs < est : dS < 0.);  // T = 0: dS < 0 decides (:49-50)
+                    const unsigned long long b_far = __builtin_amdgcn_ballot_w64(!warm || fabs(lhs - est) > c_tol * est);
+                    if (__builtin_expect((~b_far & b_can) != 0ull, 0)) {  // a verdict too close to call
+                        const unsigned long long exact = __builtin_amdgcn_ballot_w64(lhs < accu1 * exp(z));
+                        b_acc = (b_acc & b_far) | (exact & ~b_far);
+                    }
+                    // verdicts, in step order: bits 15 / 31 / 47 / 63 -> bits 0..3
+                    auto rows4 = [](unsigned long long b) -> uint32_t {
+                        const unsigned long long x = b >> 15;
+                        return (uint32_t)(x | (x >> 15) | (x >> 30) | (x >> 45)) & 0xfu;
+                    };
+                    const uint32_t can4 = rows4(b_can), mv4 = can4 & rows4(b_acc & kRowRep), selfok4 = rows4(b_selfok);
+                    uint32_t moved = mv4 & 1u, commit = 1u;
+                    {
+                        const uint32_t c01 = (clash_bits >> 1) & 1u, c02 = (clash_bits >> 2) & 1u, c03 = (clash_bits >> 3) & 1u;
+                        const uint32_t c12 = (clash_bits >> 6) & 1u, c13 = (clash_bits >> 7) & 1u, c23 = (clash_bits >> 11) & 1u;
+                        const uint32_t m0 = moved & 1u;
+                        const uint32_t k1c = sflag(nst - 1u) & ((m0 & c01) ^ 1u);  // (nst >= 2)
+                        const uint32_t m1 = k1c & (mv4 >> 1) & 1u;
+                        const uint32_t k2c = k1c & (nst > 2u ? 1u : 0u) & ((m0 & c02) ^ 1u) & ((m1 & c12) ^ 1u);
+                        const uint32_t m2 = k2c & (mv4 >> 2) & 1u;
+                        const uint32_t k3c = k2c & (nst > 3u ? 1u : 0u) & ((m0 & c03) ^ 1u) & ((m1 & c13) ^ 1u) & ((m2 & c23) ^ 1u);
+                        const uint32_t m3 = k3c & (mv4 >> 3) & 1u;
+                        commit = 1u | (k1c << 1) | (k2c << 2) | (k3c << 3);
+                        moved = m0 | (m1 << 1) | (m2 << 2) | (m3 << 3);
+                    }
+                    acc_chunk += (uint32_t)__builtin_popcount(moved | (commit & selfok4));
+                    if ((TM ? (moved | (commit & selfok4)) : moved) != 0u) {
+                        // ---- apply_mcmc_moves, blockmodel.cc:461-503, for the steps that move: their rows of m differ ----
+                        unsigned long long movers = 0ull;
+                        if (moved & 1u) movers |= 0x000000000000ffffull;
+                        if (moved & 2u) movers |= 0x00000000ffff0000ull;
+                        if (moved & 4u) movers |= 0x0000ffff00000000ull;
+                        if (moved & 8u) movers |= 0xffff000000000000ull;
+                        wfence();
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & lanes_koth32_lo)) {  // k == 0: rewrites the same values
+                            mq[a_rt0] = m_rt_raw0 - k0;
+                            mq[a_st0] = m_st_raw0 + k0;
+                        }
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & lanes_koth32_hi)) {
+                            mq[a_rt1] = m_rt_raw1 - k1;
+                            mq[a_st1] = m_st_raw1 + k1;
+                        }
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0030003000300030ull))  // lanes 4, 5 of a row: eta_r - 1, eta_s + 1
+                            eta_l[e_idx] = (uint32_t)(ee + ((int)(lane & 1u) * 2 - 1));
+                        if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0001000100010001ull)) new_lab[qs] = (uint8_t)(own_base + s_loc);
+                        // the register copies of m_r / n_r, sum dS (:500) and the early-stop bookkeeping, in step order
+#pragma unroll
+                        for (uint32_t g = 0; g < 4u; ++g) {
+                            if ((moved >> g) & 1u) {
+                                const uint32_t rg = readlane(r_loc, 16u * g), sg = readlane(s_loc, 16u * g), dg = readlane(deg, 16u * g);
+                                const int dl = (int)min(lb ^ rg, 1u) - (int)min(lb ^ sg, 1u);  // +1 on lane s, -1 on lane r
+                                mr_own += __mul24((int)dg, dl);
+                                nr_own += dl;
+                                cum_l0 += readlane(dS, 16u * g + 15u);
+                                if constexpr (TM) new_minimum(q + g);
+                            } else if (TM && (((commit & selfok4) >> g) & 1u)) {
+                                new_minimum(q + g);  // an accepted r == s step (see new_minimum)
+                            }
+                        }
+                        wfence();
+                    }
+                    return (uint32_t)__builtin_popcount(commit);
+                };
+                auto quad32_loop = [&](auto tm) {
+                    uint32_t q = 0;
+                    acc_chunk = 0;
+                    while (q < cnt) {
+                        const uint32_t four = (uint32_t)(gen_mask >> q) & 0xfu;
+                        if (__builtin_expect((four & 1u) != 0u, 0)) {
+                            step_general(q, T_of_step(q));
+                            q += 1u;
+                        } else {  // the steps up to the next one that needs the general path, or to the end of the chunk
+                            const uint32_t nst = min(min((uint32_t)__builtin_ctz(four | 0x10u), 4u), cnt - q);
+                            q += step_quad32(tm, q, nst);
+                        }
+                    }
+                    acc_l0 += (unsigned long long)acc_chunk;
+                };
                 // ---- eight steps per pass (both block counts <= 8) ----
                 // step_quad once more: group g of eight lanes evaluates step q + g.  The 28 pairwise tests fill the wave (lane
                 // 8 j + i: earlier step i, later step j), so byte j of their ballot is the set of earlier steps step j clashes
@@ -1468,32 +1606,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double a1 = k * (m_rt - k + eps) * inv_blk;
                     const double accu0 = butterfly_groups8(a0);
                     const double accu1 = butterfly_groups8(a1);
-                    double lq;
-                    {
-                        const int qk2 = qk < qn ? qk : qn;
-                        const double nd = (double)qn, kd = (double)qk2;
-                        const double k2 = kd * kd;
-                        const bool direct = qn > kQNmax && k2 > c_576 * nd;
-                        if (__builtin_amdgcn_ballot_w64(qn > kQNmax) == 0) {
-                            lq = log_q_table(tab, qn, qk2);
-                        } else if (__builtin_amdgcn_ballot_w64(!direct) == 0) {
-                            double sq, rr;
-                            sqrt_rsqrt(nd, sq, rr);
-                            lq = log_q_closed(kd, sq, rr, logn, lqc);
-                        } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= c_169 * nd)) == 0) {
-                            double sq, rr;
-                            sqrt_rsqrt(nd, sq, rr);
-                            lq = log_q_closed2(kd, sq, rr, logn, lqc);
-                        } else if (__builtin_amdgcn_ballot_w64(!(qn > kQNmax && k2 >= ldexp(nd, 6))) == 0) {
-                            double sq, rr;
-                            sqrt_rsqrt(nd, sq, rr);
-                            const double lq_mid = log_q_mid(kd, sq, rr, logn, lqc);
-                            const double lq_far = log_q_closed(kd, sq, rr, logn, lqc);
-                            lq = direct ? lq_far : lq_mid;
-                        } else {
-                            lq = log_q<true>(tab, qn, qk, logn);
-                        }
-                    }
+                    const double lq = hot_log_q(std::true_type{}, qn, qk, logn);
                     double d = (L1 + L2) - (L3 + L4);
                     d = d + tail_lg * sign_tail;
                     d = d + lq * sign_q;
@@ -1598,7 +1711,12 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         quad_loop(std::true_type{});
                     else
                         quad_loop(std::false_type{});
-                } else if (K32 && !K16 && pair_mode) {  // (the K <= 16 / K <= 8 kernels hold their own kind of pass only: registers)
+                } else if (Q32 && quad32_mode) {
+                    if (track_min != 0u)
+                        quad32_loop(std::true_type{});
+                    else
+                        quad32_loop(std::false_type{});
+                } else if (K32 && !K16 && !Q32 && pair_mode) {  // (the K <= 16 / K <= 8 kernels hold their own kind of pass only: registers)
                     if (track_min != 0u)
                         pair_loop(std::true_type{});
                     else
@@ -1706,12 +1824,12 @@ size_t sweep_fast_lds_bytes(uint32_t ka, uint32_t kb, uint32_t maxdeg, bool eta_
     return ((dwords > reach ? dwords : reach) * 4 + 15) & ~(size_t)15;
 }
 
-template <bool EL, bool CT, bool K32, bool K16, bool K8>
+template <bool EL, bool CT, bool K32, bool K16, bool K8, bool Q32 = false>
 static hipError_t launch_fast_variant3(const SweepParams& p, size_t lds_bytes, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)sweep_fast_kernel<EL, CT, K32, K16, K8>,
+    hipError_t e = hipFuncSetAttribute((const void*)sweep_fast_kernel<EL, CT, K32, K16, K8, Q32>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((sweep_fast_kernel<EL, CT, K32, K16, K8>), dim3(p.n_chains), dim3(2 * kWave), lds_bytes, stream, p);
+    hipLaunchKernelGGL((sweep_fast_kernel<EL, CT, K32, K16, K8, Q32>), dim3(p.n_chains), dim3(2 * kWave), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
@@ -1722,6 +1840,7 @@ static hipError_t launch_fast_variant(const SweepParams& p, size_t lds_bytes, hi
     const uint32_t depth = p.pair_steps < p.pass_depth ? p.pair_steps : p.pass_depth;  // 0 / 1 / 2 / 3: one, two, four, eight steps per pass
     if (p.ka <= 8u && p.kb <= 8u && depth >= 3u) return launch_fast_variant3<EL, CT, true, true, true>(p, lds_bytes, stream);
     if (p.ka <= 16u && p.kb <= 16u && depth >= 2u) return launch_fast_variant3<EL, CT, true, true, false>(p, lds_bytes, stream);
+    if (p.ka <= 32u && p.kb <= 32u && depth >= 2u) return launch_fast_variant3<EL, CT, true, false, false, true>(p, lds_bytes, stream);
     return (p.ka <= 32u && p.kb <= 32u) ? launch_fast_variant3<EL, CT, true, false, false>(p, lds_bytes, stream)
                                         : launch_fast_variant3<EL, CT, false, false, false>(p, lds_bytes, stream);
 }

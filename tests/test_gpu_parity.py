@@ -307,6 +307,55 @@ def test_four_and_eight_steps_per_pass_equal_the_serial_chain(monkeypatch):
             assert g.get_entropy()[c] == pytest.approx(o.get_entropy(), rel=1e-9)
 
 
+@pytest.mark.parametrize("ka,kb,eps", [(32, 32, 1.0), (17, 29, 0.5), (24, 7, 1.0)])
+def test_four_steps_per_pass_with_two_blocks_per_lane(ka, kb, eps, monkeypatch):
+    """17..32 blocks of a type: a launch whose pass depth is four runs step_quad32 -- four steps in the four 16-lane rows of
+    the wave, every lane holding two blocks.  The chains equal their oracle runs and the same chains held
+    to two steps and to one step per pass: from a randomised start (most steps move, most followers clash) and from the planted
+    partition (most proposals are r == s, passes commit all four), at constant temperatures and under cooling schedules with
+    the early stop armed and the greedy tail (T = 0), with chunks that end mid-pass (class sizes not multiples of 64)."""
+    na, nb = 24_011, 23_003
+    rowptr, col = _random_graph(15, na, nb, 480_000, ka, kb)
+    n = na + nb
+    planted = O.contiguous_labels(na, nb, ka, kb)
+    mh = B.MetropolisHasting()
+    chains = 5
+    runs = [("constant", [1.0], 2 * n, BIG), ("constant", [0.6], n, BIG), ("exponential", [1.5, 0.99997], 4 * n, n // 2),
+            ("abrupt_cool", [1.5 * n], 3 * n, BIG), ("linear", [1.2, 1.0 / (2 * n)], 2 * n, BIG), ("constant", [1.0], n + 77, BIG)]
+    for start in ("randomised", "planted"):
+        out = {}
+        for pin in ("4", "2", "single"):
+            monkeypatch.delenv("BISBM_SINGLE_STEPS", raising=False)
+            monkeypatch.delenv("BISBM_PASS_DEPTH", raising=False)
+            if pin == "single":
+                monkeypatch.setenv("BISBM_SINGLE_STEPS", "1")
+            else:
+                monkeypatch.setenv("BISBM_PASS_DEPTH", pin)
+            g = gpu_model(rowptr, col, na, nb, ka, kb, eps, planted, n_chains=chains, rng="philox", seed=78, first_chain_id=1)
+            g.shuffle_bisbm() if start == "randomised" else g.init_bisbm()
+            rates = [np.atleast_1d(mh.anneal(g, s, kw, dur, aw)).copy() for s, kw, dur, aw in runs]
+            out[pin] = (g, rates, g.last_counts())
+        monkeypatch.delenv("BISBM_SINGLE_STEPS", raising=False)
+        monkeypatch.delenv("BISBM_PASS_DEPTH", raising=False)
+        g, rates, counts = out["4"]
+        for pin in ("2", "single"):
+            h, rates_h, counts_h = out[pin]
+            for a, b in zip(rates, rates_h):
+                assert (a == b).all(), (start, pin)
+            assert all((x == y).all() for x, y in zip(counts, counts_h))
+            for c in range(chains):
+                assert (g.get_memberships(c) == h.get_memberships(c)).all(), (start, pin, c)
+            assert (g.get_entropy() == h.get_entropy()).all()  # same sum, same order of additions
+        for c in (0, chains - 1):
+            o = O.OracleModel(rowptr, col, na, nb, ka, kb, eps, planted)
+            o.seed_philox(78, 1 + c)
+            o.shuffle_bisbm() if start == "randomised" else o.init_bisbm()
+            for (s, kw, dur, aw), r in zip(runs, rates):
+                assert o.anneal(s, kw, dur, aw) == r[c], (start, s, c)
+            assert_state_equal(g, o, c)
+            assert g.get_entropy()[c] == pytest.approx(o.get_entropy(), rel=1e-9)
+
+
 def test_pass_depth_is_chosen_from_timed_launches_and_never_changes_results(monkeypatch, capfd):
     """With few blocks the depth of the passes (two / four / eight steps) is chosen per launch from the measured speed of the
     launches, and a long constant-temperature call runs as several launches so that the choice can follow the chain.  The
