@@ -247,13 +247,14 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
         (uint32_t)__builtin_amdgcn_readfirstlane(((!CT || T_const < 1.) && p.steps_await <= p.call_duration) ? 1 : 0);
     // constants of the hot step (log_q closed form, accept filter)
     BISBM_PIN(c_l2e, 0x1.71547652b82fep+0);        // log2(e)
-    BISBM_PIN(c_tol, 1e-5);                        // accept filter margin
+    double c_tol = 1e-5;                           // accept filter margin
+    if (!(Q32 && !EL && !CT)) __asm__ volatile("" : "+v"(c_tol));  // (pinned, except in the variant where registers are scarcest)
     LogQConsts lqc = log_q_consts();  // log_q closed form
     __asm__ volatile("" : "+v"(lqc.nc0l2e), "+v"(lqc.c1c0), "+v"(lqc.c1), "+v"(lqc.c2c0), "+v"(lqc.lfc));
     double c_576 = 576.0;                          // 24^2: tier test k^2 > 576 n
-    if (K32 || CT) __asm__ volatile("" : "+v"(c_576));  // (pinned like the others, except where registers are scarcest)
+    if ((K32 && !Q32) || CT) __asm__ volatile("" : "+v"(c_576));  // (pinned like the others, except where registers are scarcest)
     double c_169 = 169.0;                          // 13^2: tier test k^2 >= 169 n
-    if (K32) __asm__ volatile("" : "+v"(c_169));   // (pinned like the others, except in the K > 32 variant: registers)
+    if (K32 && !Q32) __asm__ volatile("" : "+v"(c_169));   // (pinned like the others, except in the two-blocks-per-lane variants: registers)
     uint64_t sweeps_done = 0;
     // Sum of accepted dS (blockmodel_t::entropy_) and accepted count: lane 0's copy is the value.  They are bumped
     // inside the lane-0 region of an accepted step (a vector add under the execution mask, no LDS round trip).
@@ -1220,22 +1221,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                             if (b_selfok != 0ull) new_minimum(q + ((uint32_t)__builtin_ctzll(b_selfok) >> 4));  // (the first accepted one; the sum does not change)
                         return nst;
                     }
-                    // pairwise: would step i, if it moves its node, touch what step j read?  (lane 4 i + j, any row)
-                    uint32_t clash_bits;
-                    {
-                        const int li = (int)(((lane >> 2) & 3u) << 6), lj = (int)((lane & 3u) << 6);  // lane 16 i, lane 16 j
-                        const uint32_t r_i = (uint32_t)__builtin_amdgcn_ds_bpermute(li, (int)r_loc);
-                        const uint32_t s_i = (uint32_t)__builtin_amdgcn_ds_bpermute(li, (int)s_loc);
-                        const uint32_t r_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)r_loc);
-                        const uint32_t s_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)s_loc);
-                        const uint32_t t_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)t_loc);
-                        const uint32_t k_i_tj = (uint32_t)__builtin_amdgcn_ds_bpermute(li + (int)(t_j << 2), (int)kk);  // k of step i at block t_j
-                        const uint32_t set_i = (1u << r_i) | (1u << s_i), set_j = (1u << r_j) | (1u << s_j);
-                        const uint32_t lo = min(r_i, s_i), hi = max(r_i, s_i);
-                        const uint32_t between = ((1u << hi) - 1u) & ~((2u << lo) - 1u);  // blocks strictly between r_i and s_i
-                        const bool clash = (set_i & set_j) != 0u || (((between >> s_j) & 1u) != 0u && k_i_tj != 0u);
-                        clash_bits = (uint32_t)__builtin_amdgcn_ballot_w64(clash) & 0xffffu;  // bit 4 i + j
-                    }
                     const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
                     const uint32_t a_st = mq_at(s_loc, lb);
                     const int32_t m_st_raw = mq[a_st];
@@ -1257,6 +1242,26 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double accu0 = butterfly_rows16(a0);  // every lane of a row: the row's sum
                     const double accu1 = butterfly_rows16(a1);
                     const double lq = hot_log_q(std::true_type{}, qn, qk, logn);
+                    // pairwise: would step i, if it moves its node, touch what step j read?  (lane 4 i + j, any row)
+                    // (worked out while the table gathers are in flight: after ALL of them have been issued -- the table tier of log_q is one more --, see step_pair)
+                    uint32_t clash_bits;
+                    {
+                        uint32_t r_c = r_loc, s_c = s_loc, t_c = t_loc;
+                        __asm__ volatile("" : "+v"(r_c), "+v"(s_c), "+v"(t_c)::"memory");
+                        const int li = (int)(((lane >> 2) & 3u) << 6), lj = (int)((lane & 3u) << 6);  // lane 16 i, lane 16 j
+                        const uint32_t r_i = (uint32_t)__builtin_amdgcn_ds_bpermute(li, (int)r_c);
+                        const uint32_t s_i = (uint32_t)__builtin_amdgcn_ds_bpermute(li, (int)s_c);
+                        const uint32_t r_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)r_c);
+                        const uint32_t s_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)s_c);
+                        const uint32_t t_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)t_c);
+                        const uint32_t k_i_tj = (uint32_t)__builtin_amdgcn_ds_bpermute(li + (int)(t_j << 2), (int)kk);  // k of step i at block t_j
+                        const uint32_t set_i = (1u << r_i) | (1u << s_i), set_j = (1u << r_j) | (1u << s_j);
+                        const uint32_t lo = min(r_i, s_i), hi = max(r_i, s_i);
+                        const uint32_t between = ((1u << hi) - 1u) & ~((2u << lo) - 1u);  // blocks strictly between r_i and s_i
+                        // (bit arithmetic, no short-circuit: a lane-divergent `||` becomes a branch over the execution mask)
+                        const uint32_t in_between = (between >> s_j) & min(k_i_tj, 1u);
+                        clash_bits = (uint32_t)__builtin_amdgcn_ballot_w64(((set_i & set_j) | in_between) != 0u) & 0xffffu;  // bit 4 i + j
+                    }
                     double d = (L1 + L2) - (L3 + L4);
                     d = d + tail_lg * sign_tail;
                     d = d + lq * sign_q;
@@ -1411,8 +1416,14 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double tail_lg = tab_at(tab.lg, tail_idx);
                     const double L2_0 = tab_at(tab.lg, (uint32_t)(m_st0 + 1)), L4_0 = tab_at(tab.lg, (uint32_t)(m_st0 + 1) + kk0);
                     const double L2_1 = tab_at(tab.lg, (uint32_t)(m_st1 + 1)), L4_1 = tab_at(tab.lg, (uint32_t)(m_st1 + 1) + kk1);
+                    // the lane's two leaves of each Hastings sum, added first (level 16 of their tree)
+                    const double a0 = k0 * (m_st0 + eps) * invq_lo + k1 * (m_st1 + eps) * invq_hi;
+                    const double a1 = k0 * (m_rt0 - k0 + eps) * invq_lo + k1 * (m_rt1 - k1 + eps) * invq_hi;
+                    const double accu0 = butterfly_rows16(a0);  // every lane of a row: the row's sum
+                    const double accu1 = butterfly_rows16(a1);
+                    const double lq = hot_log_q(std::false_type{}, qn, qk, logn);
                     // pairwise: would step i, if it moves its node, touch what step j read?  (lane 4 i + j, any row)
-                    // (worked out while the table gathers are in flight: after they have been issued, see step_pair)
+                    // (worked out while the table gathers are in flight: after ALL of them have been issued -- the table tier of log_q is one more --, see step_pair)
                     uint32_t clash_bits;
                     {
                         uint32_t r_c = r_loc, s_c = s_loc, t_c = t_loc;
@@ -1434,12 +1445,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         const uint32_t in_between = (between >> s_j) & min(k_i_tj, 1u);
                         clash_bits = (uint32_t)__builtin_amdgcn_ballot_w64(((set_i & set_j) | in_between) != 0u) & 0xffffu;  // bit 4 i + j
                     }
-                    // the lane's two leaves of each Hastings sum, added first (level 16 of their tree)
-                    const double a0 = k0 * (m_st0 + eps) * invq_lo + k1 * (m_st1 + eps) * invq_hi;
-                    const double a1 = k0 * (m_rt0 - k0 + eps) * invq_lo + k1 * (m_rt1 - k1 + eps) * invq_hi;
-                    const double accu0 = butterfly_rows16(a0);  // every lane of a row: the row's sum
-                    const double accu1 = butterfly_rows16(a1);
-                    const double lq = hot_log_q(std::false_type{}, qn, qk, logn);
                     double d0 = (L1_0 + L2_0) - (L3_0 + L4_0);
                     d0 = d0 + tail_lg * sign_tail;  // the scalar terms sit in leaves 0..7 / 0..3: the lane's lower leaf
                     d0 = d0 + lq * sign_q;
@@ -1571,21 +1576,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                             if (b_selfok != 0ull) new_minimum(q + ((uint32_t)__builtin_ctzll(b_selfok) >> 3));
                         return nst;
                     }
-                    unsigned long long clash_bits;  // byte j, bit i: step i (earlier), if it moves, touches what step j read
-                    {
-                        const int li = (int)((lane & 7u) << 5), lj = (int)((lane >> 3) << 5);  // lane 8 i, lane 8 j
-                        const uint32_t r_i = (uint32_t)__builtin_amdgcn_ds_bpermute(li, (int)r_loc);
-                        const uint32_t s_i = (uint32_t)__builtin_amdgcn_ds_bpermute(li, (int)s_loc);
-                        const uint32_t r_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)r_loc);
-                        const uint32_t s_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)s_loc);
-                        const uint32_t t_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)t_loc);
-                        const uint32_t k_i_tj = (uint32_t)__builtin_amdgcn_ds_bpermute(li + (int)(t_j << 2), (int)kk);
-                        const uint32_t set_i = (1u << r_i) | (1u << s_i), set_j = (1u << r_j) | (1u << s_j);
-                        const uint32_t lo = min(r_i, s_i), hi = max(r_i, s_i);
-                        const uint32_t between = ((1u << hi) - 1u) & ~((2u << lo) - 1u);
-                        const bool clash = (set_i & set_j) != 0u || (((between >> s_j) & 1u) != 0u && k_i_tj != 0u);
-                        clash_bits = __builtin_amdgcn_ballot_w64(clash);
-                    }
                     const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);
                     const uint32_t a_st = mq_at(s_loc, lb);
                     const int32_t m_st_raw = mq[a_st];
@@ -1607,6 +1597,23 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double accu0 = butterfly_groups8(a0);
                     const double accu1 = butterfly_groups8(a1);
                     const double lq = hot_log_q(std::true_type{}, qn, qk, logn);
+                    unsigned long long clash_bits;  // byte j, bit i: step i (earlier), if it moves, touches what step j read
+                    {  // (worked out while the table gathers are in flight: after ALL of them have been issued -- the table tier of log_q is one more --, see step_pair)
+                        uint32_t r_c = r_loc, s_c = s_loc, t_c = t_loc;
+                        __asm__ volatile("" : "+v"(r_c), "+v"(s_c), "+v"(t_c)::"memory");
+                        const int li = (int)((lane & 7u) << 5), lj = (int)((lane >> 3) << 5);  // lane 8 i, lane 8 j
+                        const uint32_t r_i = (uint32_t)__builtin_amdgcn_ds_bpermute(li, (int)r_c);
+                        const uint32_t s_i = (uint32_t)__builtin_amdgcn_ds_bpermute(li, (int)s_c);
+                        const uint32_t r_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)r_c);
+                        const uint32_t s_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)s_c);
+                        const uint32_t t_j = (uint32_t)__builtin_amdgcn_ds_bpermute(lj, (int)t_c);
+                        const uint32_t k_i_tj = (uint32_t)__builtin_amdgcn_ds_bpermute(li + (int)(t_j << 2), (int)kk);
+                        const uint32_t set_i = (1u << r_i) | (1u << s_i), set_j = (1u << r_j) | (1u << s_j);
+                        const uint32_t lo = min(r_i, s_i), hi = max(r_i, s_i);
+                        const uint32_t between = ((1u << hi) - 1u) & ~((2u << lo) - 1u);
+                        const uint32_t in_between = (between >> s_j) & min(k_i_tj, 1u);  // (bit arithmetic: no lane-divergent branch)
+                        clash_bits = __builtin_amdgcn_ballot_w64(((set_i & set_j) | in_between) != 0u);
+                    }
                     double d = (L1 + L2) - (L3 + L4);
                     d = d + tail_lg * sign_tail;
                     d = d + lq * sign_q;
