@@ -382,9 +382,11 @@ def main():
     sync()
     t0 = time.perf_counter()
     kernel_ms, updates = 0.0, 0
+    pass_steps = []  # steps per pass of each timed launch (chosen per launch by the library; the chain does not depend on it)
     for _ in range(args.steps):
         sweep()
         ms, upd = model.last_sweep_timing()
+        pass_steps.append(model.last_pass_steps())
         note("timed")
         kernel_ms += ms
         updates += upd
@@ -466,7 +468,7 @@ def main():
             ms, upd = model.last_sweep_timing()
             ems += ms
             eupd += upd
-        equil = {"updates_per_s_per_gpu": eupd / (ems / 1e3), "avg_launch_ms": ems / 3,
+        equil = {"updates_per_s_per_gpu": eupd / (ems / 1e3), "avg_launch_ms": ems / 3, "steps_per_pass": model.last_pass_steps(),
                  "accepted_fraction": float(model.last_counts()[0].sum()) / (n * args.sweeps_per_step * shard.n_local),
                  "what": "same graph and chains, started on the planted partition (near the posterior mode), 3 sweeps "
                          "to settle, 3 timed (kernel time)"}
@@ -552,6 +554,7 @@ def main():
                                                           else "%d sweeps (of n node updates) of every chain in one launch" % args.sweeps_per_step),
                 "spinup_sweeps_before_warmup": len(spin_ms),
                 "accepted_fraction_last_timed_sweep": accepted_frac,
+                "steps_per_pass_of_the_timed_launches": {str(k): pass_steps.count(k) for k in sorted(set(pass_steps))},
                 "parallelism": "chains sharded, no collective in the sweep path",
                 "collective_backend": (backend if world > 1 else None), "collective_backend_note": backend_note,
             },

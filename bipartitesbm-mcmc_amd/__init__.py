@@ -75,6 +75,7 @@ ABI = {
     "bisbm_get_sizes": (C.c_int, [C.c_void_p, _u64p, _u64p, _u32p, _u32p]),
     "bisbm_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bisbm_last_sweep_timing": (C.c_int, [C.c_void_p, _f64p, _u64p]),
+    "bisbm_last_pass_steps": (C.c_int, [C.c_void_p, _u32p]),
     "bisbm_debug_log_q": (C.c_int, [C.c_void_p, _i32p, _i32p, C.c_size_t, C.c_int, _f64p]),
     "bisbm_io_read_edge_list": (C.c_long, [C.c_char_p, C.POINTER(_u64p), C.POINTER(_u64p)]),
     "bisbm_io_read_memberships": (C.c_long, [C.c_char_p, C.POINTER(_u32p)]),
@@ -467,6 +468,12 @@ class BlockModel:
         ms, upd = C.c_double(), C.c_uint64()
         self._check(self._L.bisbm_last_sweep_timing(self._h, C.byref(ms), C.byref(upd)))
         return ms.value, upd.value
+
+    def last_pass_steps(self):
+        """Steps per pass of the last sweep launch (1, 2, 4, 8): chosen per launch, never changes the chain."""
+        k = C.c_uint32()
+        self._check(self._L.bisbm_last_pass_steps(self._h, C.byref(k)))
+        return k.value
 
     # -- marginals (README.md:49-53)
     @property

@@ -196,6 +196,7 @@ int multi_anneal(bisbm_engine* h, int schedule, const float kwargs[2], uint64_t 
     for (bisbm_engine* d : h->devs) {  // the devices run side by side: the call lasted as long as the slowest one
         h->last_kernel_ms = std::max(h->last_kernel_ms, d->last_kernel_ms);
         h->last_updates += d->last_updates;
+        h->last_pass_steps = std::max(d == h->devs[0] ? 0u : h->last_pass_steps, d->last_pass_steps);
     }
     return rc;
 }

@@ -237,6 +237,7 @@ struct bisbm_engine {
     // last sweep timing
     double last_kernel_ms = 0;
     uint64_t last_updates = 0;
+    uint32_t last_pass_steps = 0;  // steps per pass of the last sweep launch (1, 2, 4, 8)
     // production kernel, both block counts <= 16: which depth of pass (1 / 2 / 3 = two / four / eight steps) runs how fast
     // HERE (updates per ms of the launches so far, 0 = not tried yet), and how many launches ago another one was tried
     double pass_speed[4] = {0, 0, 0, 0};
@@ -345,6 +346,9 @@ int rebuild_state(bisbm_engine* h) {
     HIPCHK(h, launch_state_build(bp, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->state_ready = true;
+    // (a partition put in place from outside -- init, shuffle, merges, splits: the pass depths are measured afresh, see bisbm_anneal)
+    for (double& sp : h->pass_speed) sp = 0;
+    h->pass_launches = 0;
     return BISBM_OK;
 }
 
@@ -728,6 +732,7 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
             }
             h->last_kernel_ms = std::max(h->last_kernel_ms, g->last_kernel_ms);
             h->last_updates += g->last_updates;
+            h->last_pass_steps = gi == 0 ? g->last_pass_steps : std::max(h->last_pass_steps, g->last_pass_steps);
             if (acc_rate_out)
                 for (size_t j = 0; j < rates[gi].size(); ++j) acc_rate_out[g->ridx[j]] = rates[gi][j];
         }
@@ -965,6 +970,14 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
                 depth = pd[0] == '2' ? 1u : pd[0] == '4' ? std::min(2u, max_depth) : pd[0] == '8' ? max_depth : depth;
         }
         p.pass_depth = depth;
+        {  // (what launch_sweep_fast picks from these numbers)
+            const uint32_t d = std::min(p.pair_steps, p.pass_depth);
+            const bool cold = schedule == SCHED_CONSTANT && kwargs[0] == 0.f;  // T = 0 throughout: general steps only
+            h->last_pass_steps = (!fast || cold) ? 1u
+                                 : (h->ka <= 8 && h->kb <= 8 && d >= 3u) ? 8u
+                                 : (h->ka <= 32 && h->kb <= 32 && d >= 2u) ? 4u
+                                 : p.pair_steps != 0u ? 2u : 1u;
+        }
         HIPCHK(h, hipEventRecord(h->ev0, h->stream));
         if (fast)
             HIPCHK(h, launch_sweep_fast(p, lds, h->stream));
@@ -1267,6 +1280,12 @@ int bisbm_last_sweep_timing(bisbm_handle h, double* kernel_ms, uint64_t* node_up
     if (!h) return BISBM_ERR_INVALID_ARG;
     if (kernel_ms) *kernel_ms = h->last_kernel_ms;
     if (node_updates) *node_updates = h->last_updates;
+    return BISBM_OK;
+}
+
+int bisbm_last_pass_steps(bisbm_handle h, uint32_t* steps_per_pass) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    if (steps_per_pass) *steps_per_pass = h->last_pass_steps;
     return BISBM_OK;
 }
 

@@ -204,6 +204,12 @@ int bisbm_set_stream(bisbm_handle h, void *hip_stream);
  * launch stream, and the number of node updates it executed (all chains). */
 int bisbm_last_sweep_timing(bisbm_handle h, double *kernel_ms, uint64_t *node_updates);
 
+/* How many steps the passes of the last sweep launch evaluated at once (1, 2, 4 or 8; the largest over the
+ * handle's devices / shape groups).  With at most 32 blocks of a type the depth is chosen per launch from the
+ * measured speed of earlier launches; the chain does not depend on it.  Diagnostic: no
+ * counterpart in the reference. */
+int bisbm_last_pass_steps(bisbm_handle h, uint32_t *steps_per_pass);
+
 /* Device numerics probe (tests): evaluates log_q(n[i], k[i]) on the device (int_part.hh:27-37).
  * fast = 0: the literal evaluation (mt19937-compat mode, entropy()); fast = 1: the Philox-mode
  * evaluation, which uses a closed form of get_v/spence for k/sqrt(n) > 21. */

@@ -413,6 +413,47 @@ def test_pass_depth_is_chosen_from_timed_launches_and_never_changes_results(monk
     assert (o.last_accepted, o.last_sweeps) == (int(ref[3][0][3]), int(ref[3][1][3]))
 
 
+def test_last_pass_steps_reports_the_kind_of_pass_and_a_new_partition_is_measured_afresh(monkeypatch):
+    """bisbm_last_pass_steps: 1 / 2 / 4 / 8 steps per pass of the last launch -- what a pinned depth asks for (capped by what the
+    block counts allow: 20 + 31 blocks: two or four; 40 + 33: two; 5 + 7: up to eight), 1 for the generic kernel (compat mode).
+    The measured speeds of the depths belong to a partition: init / shuffle forget them, so the next launches try the depths
+    again (the bench's equilibrated-start leg relies on it)."""
+    mh = B.MetropolisHasting()
+    na = nb = 6_000
+    for ka, kb, pins in ((20, 31, {"2": 2, "4": 4, "8": 4}), (40, 33, {"2": 2, "4": 2}), (5, 7, {"2": 2, "4": 4, "8": 8})):
+        rowptr, col = _random_graph(21, na, nb, 90_000, ka, kb)
+        lab = O.contiguous_labels(na, nb, ka, kb)
+        for pin, want in pins.items():
+            monkeypatch.setenv("BISBM_PASS_DEPTH", pin)
+            g = gpu_model(rowptr, col, na, nb, ka, kb, 1.0, lab, n_chains=3, rng="philox", seed=5)
+            g.shuffle_bisbm()
+            assert g.last_pass_steps() == 0  # nothing launched yet
+            mh.anneal(g, "constant", [1.0], 2 * (na + nb), BIG)
+            assert g.last_pass_steps() == want, (ka, kb, pin)
+        monkeypatch.setenv("BISBM_SINGLE_STEPS", "1")
+        g = gpu_model(rowptr, col, na, nb, ka, kb, 1.0, lab, n_chains=3, rng="philox", seed=5)
+        g.shuffle_bisbm()
+        mh.anneal(g, "constant", [1.0], na + nb, BIG)
+        assert g.last_pass_steps() == 1
+        monkeypatch.delenv("BISBM_SINGLE_STEPS")
+    monkeypatch.delenv("BISBM_PASS_DEPTH")
+    c = gpu_model(rowptr, col, na, nb, 5, 7, 1.0, lab, n_chains=1, rng="compat", seed=5, gen_seed=6)
+    c.shuffle_bisbm()
+    mh.anneal(c, "constant", [1.0], na + nb, BIG)
+    assert c.last_pass_steps() == 1
+    # free choice on 20 + 31 blocks: both depths are tried, again after every new partition
+    rowptr, col = _random_graph(21, na, nb, 90_000, 20, 31)
+    lab = O.contiguous_labels(na, nb, 20, 31)
+    g = gpu_model(rowptr, col, na, nb, 20, 31, 1.0, lab, n_chains=3, rng="philox", seed=5)
+    for start in (g.shuffle_bisbm, g.init_bisbm):
+        start()
+        tried = []
+        for _ in range(2):
+            mh.anneal(g, "constant", [1.0], na + nb, BIG)
+            tried.append(g.last_pass_steps())
+        assert sorted(tried) == [2, 4], tried
+
+
 @pytest.mark.parametrize("roles", ["claims", "1", "2"])
 def test_either_wave_can_step(roles, monkeypatch):
     """The production kernel settles at start which of a workgroup's two waves steps (per-SIMD claims); whichever it is
