@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 /* 2: bisbm_get_ka_kb_chain; KA + KB above 256 (wide mode); handles whose chains differ in shape.
- * 3: bisbm_check_shape; several devices behind one handle (bisbm_create_multi).  Additions only. */
+ * 3: bisbm_check_shape; several devices behind one handle (bisbm_create_multi); bisbm_last_pass_steps.  Additions only. */
 #define BISBM_ABI_VERSION 3
 
 typedef struct bisbm_engine *bisbm_handle;
