@@ -9,6 +9,9 @@ mkdir -p $OUT; export TMPDIR=/tmp
 ARGS="--no-cpu-baseline --no-extras $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --steps 6 --warmup 2 $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
 find $OUT/kt -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+# the counter passes run the kind of pass the bench line's timed launches run (two steps per pass at 32 + 32 blocks from a
+# randomised start: config.steps_per_pass_of_the_timed_launches); left free, the first launches of a process try every depth
+export BISBM_PASS_DEPTH=${PMC_PASS_DEPTH:-2}
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ_INSTS_SMEM" \
