@@ -241,6 +241,8 @@ struct bisbm_engine {
     // production kernel, both block counts <= 16: which depth of pass (1 / 2 / 3 = two / four / eight steps) runs how fast
     // HERE (updates per ms of the launches so far, 0 = not tried yet), and how many launches ago another one was tried
     double pass_speed[4] = {0, 0, 0, 0};
+    double pass_acc[4] = {-1, -1, -1, -1};  // accepted fraction of the launch that last measured the depth
+    double last_acc = -1;                    // accepted fraction of the last launch (any depth)
     uint32_t pass_launches = 0;
     bool pass_up = false;
     // Chains with different block counts (after a one-argument agg_merge, blockmodel.cc:208-271: every run ends where it
@@ -348,6 +350,8 @@ int rebuild_state(bisbm_engine* h) {
     h->state_ready = true;
     // (a partition put in place from outside -- init, shuffle, merges, splits: the pass depths are measured afresh, see bisbm_anneal)
     for (double& sp : h->pass_speed) sp = 0;
+    for (double& a : h->pass_acc) a = -1;
+    h->last_acc = -1;
     h->pass_launches = 0;
     return BISBM_OK;
 }
@@ -883,28 +887,33 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
             p.simd_claims = h->d_simd_claims;
         }
     }
-    // One launch, or -- production kernel, few blocks, constant temperature, no early stop in reach (nothing but the sweep
-    // counter and the sums carries over between sweeps then, and both live in the chain's scalars) -- several launches of whole
-    // sweeps.  Deep passes (four / eight steps) pay where few steps move or the blocks are many enough for movers to miss each
-    // other (2.4 x on the reference's n_1000 data set); from a random start on a large graph with few blocks nearly every step
+    // One launch, or -- production kernel, at most 32 blocks of a type -- several launches of whole sweeps, so that the depth
+    // of the passes can follow the chain.  Deep passes (four / eight steps) pay where few steps move or the blocks are many
+    // enough for movers to miss each other (2.4 x on the reference's n_1000 data set, +17 % at 32 + 32 blocks near the mode,
+    // +20 % in the cold part of a cooling schedule); from a random start on a large graph with few blocks nearly every step
     // moves, most followers clash, and two steps per pass are faster.  Which is which depends on the graph, the partition and
     // where the chain is, so it is MEASURED: every launch is timed, the depth with the best updates per ms so far runs, and
-    // every sixteenth launch tries a neighbouring depth again (a chain leaves its burn-in).  The chain is the same chain whatever
-    // runs (same Philox counters, bit-equal results).
+    // every sixteenth launch tries a neighbouring depth again (a chain leaves its burn-in, a schedule cools down).  The chain
+    // is the same chain whatever runs (same Philox counters, bit-equal results).
     // (depth 1 = two steps per pass, 2 = four -- in 16-lane rows, two blocks per lane above 16 blocks of a type --, 3 = eight)
     const uint32_t max_depth = (!fast || p.pair_steps < 2u || h->ka > 32 || h->kb > 32) ? 0u
                                : std::min<uint32_t>(p.pair_steps, (h->ka <= 8 && h->kb <= 8) ? 3u : 2u);
-    // ("no early stop in reach": at T >= 1 the count u of metropolis_hasting.cc:85-98 stays 0, so the test `u >= steps_await`
-    // after a sweep fires exactly when steps_await == 0 -- then the call ends after its FIRST sweep with rate accepted / N
-    // (:96-98) and must stay one launch; below T = 1 the count gains at most one per step)
-    const bool depth_segments = max_depth >= 2u && schedule == SCHED_CONSTANT &&
-                                ((kwargs[0] >= 1.f && steps_await > 0) || steps_await > duration_steps) && kwargs[0] > 0.f && total_sweeps >= 2;
+    // Any schedule, any steps_await: what anneal() carries from sweep to sweep -- entropy_min_, the position of the last
+    // minimum, the count of T < 1 steps, "this chain has returned" -- travels in the chain's scalars (SweepParams::resume, as for
+    // the table slices above); a chain that has returned (steps_await == 0 at T >= 1: after its FIRST sweep, :96-98) is skipped
+    // by the later launches, and the loop below ends when every chain has.  (A constant schedule at T = 0 runs general steps
+    // only: nothing to choose.)
+    const bool depth_segments = max_depth >= 2u && !(schedule == SCHED_CONSTANT && !(kwargs[0] > 0.f)) && total_sweeps >= 2;
     const bool segmented = depth_segments || tab_segments;
     std::vector<ChainScalars> sc(h->n_chains);
     std::vector<uint64_t> acc_sum(h->n_chains, 0), sweeps_sum(h->n_chains, 0);
     double ms_sum = 0;
     uint64_t updates = 0, sweeps_left = segmented ? total_sweeps : 0, sweeps_done = 0;
-    const uint64_t seg = tab_segments ? tab_seg : std::max<uint64_t>(1, (100000 + h->n - 1) / h->n);  // depth: >= 10^5 steps per chain and launch: tens of ms
+    // depth: >= 10^5 steps per chain and launch (tens of ms); table slices: what the table holds, or the depth's figure if smaller
+    // (BISBM_LAUNCH_STEPS: tests cut calls into launches of single sweeps)
+    const uint64_t launch_steps = getenv("BISBM_LAUNCH_STEPS") ? std::max<uint64_t>(1, strtoull(getenv("BISBM_LAUNCH_STEPS"), nullptr, 10)) : 100000;
+    const uint64_t depth_seg = std::max<uint64_t>(1, (launch_steps + h->n - 1) / h->n);
+    const uint64_t seg = !depth_segments ? tab_seg : tab_segments ? std::min(tab_seg, depth_seg) : depth_seg;
     // the table slice of the next launch is evaluated on the host while the current launch runs
     struct Slice {
         std::vector<double> T;
@@ -945,22 +954,29 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
         first = false;
         uint32_t depth = max_depth;
         if (max_depth >= 2u) {
+            // A measurement belongs to a regime: a depth whose figure was taken at an accepted fraction more than 0.1 away from
+            // the last launch's (a schedule cooling down, a chain leaving its burn-in) counts as not tried -- the speed of a deep
+            // pass depends on how many steps move far more than that of a two-steps pass does, so the running depth's own speed
+            // does not tell.
+            auto fresh = [&](uint32_t d) {
+                return h->pass_speed[d] > 0 && !(h->last_acc >= 0 && h->pass_acc[d] >= 0 && std::fabs(h->last_acc - h->pass_acc[d]) > 0.1);
+            };
             uint32_t best = 0;
             for (uint32_t d = 1; d <= max_depth; ++d)
-                if (h->pass_speed[d] > h->pass_speed[best] || best == 0) best = h->pass_speed[d] > 0 ? d : best;
-            // not tried yet: on small graphs the deepest first (there it won in every regime measured, and a call that cannot
-            // be split -- an early stop in reach -- runs its one launch with the first choice); on large ones
+                if (fresh(d) && (best == 0 || h->pass_speed[d] > h->pass_speed[best])) best = d;
+            // not tried yet (or not in this regime): on small graphs the deepest first (there it won in every regime measured, and
+            // a call that is too short to be split runs its one launch with the first choice); on large ones
             // the shallowest first (from a random start it is the faster one, and the next launches look further)
+            bool all_tried = true;
+            for (uint32_t d = 1; d <= max_depth; ++d) all_tried = all_tried && fresh(d);
             if (h->n <= 100000) {
                 for (uint32_t d = 1; d <= max_depth; ++d)
-                    if (h->pass_speed[d] == 0) best = d;
+                    if (!fresh(d)) best = d;
             } else {
                 for (uint32_t d = max_depth; d >= 1; --d)
-                    if (h->pass_speed[d] == 0) best = d;
+                    if (!fresh(d)) best = d;
             }
             depth = best ? best : max_depth;
-            bool all_tried = true;
-            for (uint32_t d = 1; d <= max_depth; ++d) all_tried = all_tried && h->pass_speed[d] > 0;
             if (all_tried && ++h->pass_launches >= 16u) {  // look again at a neighbour of the best
                 h->pass_launches = 0;
                 h->pass_up = !h->pass_up;  // (one side, then the other)
@@ -1001,7 +1017,12 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
         updates += upd;
         if (max_depth >= 2u && ms > 0.05f && upd > 0) {
             const double speed = (double)upd / ms;
-            h->pass_speed[depth] = h->pass_speed[depth] > 0 ? 0.5 * (h->pass_speed[depth] + speed) : speed;
+            uint64_t acc_now = 0;
+            for (uint32_t c = 0; c < h->n_chains; ++c) acc_now += sc[c].last_accepted;
+            const double acc_frac = (double)acc_now / (double)upd;
+            const bool same_regime = h->pass_speed[depth] > 0 && h->pass_acc[depth] >= 0 && std::fabs(acc_frac - h->pass_acc[depth]) <= 0.1;
+            h->pass_speed[depth] = same_regime ? 0.5 * (h->pass_speed[depth] + speed) : speed;
+            h->pass_acc[depth] = h->last_acc = acc_frac;
             if (getenv("BISBM_PASS_LOG"))
                 fprintf(stderr, "[bisbm passes] depth %u: %.3e updates/ms (two %.3e, four %.3e, eight %.3e)\n", depth, speed, h->pass_speed[1],
                         h->pass_speed[2], h->pass_speed[3]);
@@ -2132,7 +2153,7 @@ bisbm_engine* new_group(bisbm_engine* root, uint32_t ka, uint32_t kb, uint32_t c
     g->wide = g->K > 256;
     g->epsilon = root->epsilon, g->rng_mode = root->rng_mode, g->seed = root->seed, g->gen_seed = root->gen_seed;
     g->label_stride = root->label_stride;
-    for (int d = 0; d < 4; ++d) g->pass_speed[d] = 0;  // (another shape: measured afresh)
+    for (int d = 0; d < 4; ++d) g->pass_speed[d] = 0, g->pass_acc[d] = -1;  // (another shape: measured afresh)
     g->d_rowptr = root->d_rowptr, g->d_col = root->d_col, g->d_lgamma = root->d_lgamma, g->d_logtab = root->d_logtab, g->d_q = root->d_q;
     g->tab = root->tab, g->q_stride = root->q_stride, g->ent_deg = root->ent_deg, g->ent_multi = root->ent_multi;
     g->deg_count = root->deg_count;

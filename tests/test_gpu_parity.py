@@ -313,7 +313,9 @@ def test_four_steps_per_pass_with_two_blocks_per_lane(ka, kb, eps, monkeypatch):
     the wave, every lane holding two blocks.  The chains equal their oracle runs and the same chains held
     to two steps and to one step per pass: from a randomised start (most steps move, most followers clash) and from the planted
     partition (most proposals are r == s, passes commit all four), at constant temperatures and under cooling schedules with
-    the early stop armed and the greedy tail (T = 0), with chunks that end mid-pass (class sizes not multiples of 64)."""
+    the early stop armed and the greedy tail (T = 0), with chunks that end mid-pass (class sizes not multiples of 64) -- and the
+    same calls run as launches of single sweeps with the depth chosen per launch (any schedule, early stop armed or not: what
+    anneal() carries between sweeps travels in the chain's scalars)."""
     na, nb = 24_011, 23_003
     rowptr, col = _random_graph(15, na, nb, 480_000, ka, kb)
     n = na + nb
@@ -324,11 +326,14 @@ def test_four_steps_per_pass_with_two_blocks_per_lane(ka, kb, eps, monkeypatch):
             ("abrupt_cool", [1.5 * n], 3 * n, BIG), ("linear", [1.2, 1.0 / (2 * n)], 2 * n, BIG), ("constant", [1.0], n + 77, BIG)]
     for start in ("randomised", "planted"):
         out = {}
-        for pin in ("4", "2", "single"):
+        for pin in ("4", "2", "single", "free"):
             monkeypatch.delenv("BISBM_SINGLE_STEPS", raising=False)
             monkeypatch.delenv("BISBM_PASS_DEPTH", raising=False)
+            monkeypatch.delenv("BISBM_LAUNCH_STEPS", raising=False)
             if pin == "single":
                 monkeypatch.setenv("BISBM_SINGLE_STEPS", "1")
+            elif pin == "free":  # every call cut into launches of one sweep, the depth chosen per launch from the timings
+                monkeypatch.setenv("BISBM_LAUNCH_STEPS", "1")
             else:
                 monkeypatch.setenv("BISBM_PASS_DEPTH", pin)
             g = gpu_model(rowptr, col, na, nb, ka, kb, eps, planted, n_chains=chains, rng="philox", seed=78, first_chain_id=1)
@@ -337,8 +342,9 @@ def test_four_steps_per_pass_with_two_blocks_per_lane(ka, kb, eps, monkeypatch):
             out[pin] = (g, rates, g.last_counts())
         monkeypatch.delenv("BISBM_SINGLE_STEPS", raising=False)
         monkeypatch.delenv("BISBM_PASS_DEPTH", raising=False)
+        monkeypatch.delenv("BISBM_LAUNCH_STEPS", raising=False)
         g, rates, counts = out["4"]
-        for pin in ("2", "single"):
+        for pin in ("2", "single", "free"):
             h, rates_h, counts_h = out[pin]
             for a, b in zip(rates, rates_h):
                 assert (a == b).all(), (start, pin)
