@@ -56,16 +56,43 @@ def build(force=False, verbose=False):
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
+RESOURCES = os.path.join(HERE, "libbisbm_hip.resources.json")  # registers / spills / scratch per kernel of the built library
+
+
+def _resource_usage(remarks):
+    """{kernel: {"VGPRs": n, "SGPRs Spill": n, "VGPRs Spill": n, "ScratchSize [bytes/lane]": n, ...}} from the
+    compiler's -Rpass-analysis=kernel-resource-usage remarks (they do not change the generated code)."""
+    import re
+    out, cur = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z][^:]*): (\S+) \[-Rpass-analysis", line)
+        if m and cur is not None:
+            v = m.group(2)
+            cur[m.group(1).strip()] = int(v) if v.isdigit() else v
+    return out
+
+
 def _build_locked(verbose):
+    import json
     extra = os.environ.get("BISBM_EXTRA_HIPCC_FLAGS", "").split()  # diagnostic builds (e.g. -DBISBM_ABLATE=1)
-    cmd = [hipcc()] + FLAGS + extra + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc()] + FLAGS + ["-Rpass-analysis=kernel-resource-usage"] + extra + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
-    if verbose and r.stderr:
-        print(r.stderr, file=sys.stderr)
+    usage = _resource_usage(r.stderr)
+    with open(RESOURCES, "w") as fh:
+        json.dump(usage, fh, indent=1, sort_keys=True)
+    if verbose:
+        rest = "\n".join(l for l in r.stderr.splitlines() if "kernel-resource-usage" not in l and not l.lstrip().startswith(("|", "1")))
+        if rest.strip():
+            print(rest, file=sys.stderr)
+        print("%d kernels; vector registers spilled: %d" % (len(usage), sum(k.get("VGPRs Spill", 0) for k in usage.values())), file=sys.stderr)
     build_cli(verbose=verbose)
     return LIB
 

@@ -250,7 +250,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     double c_tol = 1e-5;                           // accept filter margin
     if (!(Q32 && !EL && !CT)) __asm__ volatile("" : "+v"(c_tol));  // (pinned, except in the variant where registers are scarcest)
     LogQConsts lqc = log_q_consts();  // log_q closed form
-    __asm__ volatile("" : "+v"(lqc.nc0l2e), "+v"(lqc.c1c0), "+v"(lqc.c1), "+v"(lqc.c2c0), "+v"(lqc.lfc));
+    if (!(Q32 && !EL))  // (held in vector registers for the whole kernel, except where registers are scarcest: built at the use there)
+        __asm__ volatile("" : "+v"(lqc.nc0l2e), "+v"(lqc.c1c0), "+v"(lqc.c1), "+v"(lqc.c2c0), "+v"(lqc.lfc));
     double c_576 = 576.0;                          // 24^2: tier test k^2 > 576 n
     if ((K32 && !Q32) || CT) __asm__ volatile("" : "+v"(c_576));  // (pinned like the others, except where registers are scarcest)
     double c_169 = 169.0;                          // 13^2: tier test k^2 >= 169 n

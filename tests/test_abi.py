@@ -235,3 +235,20 @@ def test_locality_order_is_a_type_preserving_bijection_that_localises(built):
     assert scrambled > 1.5 * natural and ordered < 1.15 * natural, (natural, scrambled, ordered)
     with pytest.raises(ValueError):
         B.LocalityOrder(np.array([0, 1, 5], dtype=np.uint32))
+
+
+def test_no_kernel_spills_vector_registers(built):
+    """The build records the compiler's resource usage per kernel (build.py: -Rpass-analysis=kernel-resource-usage, no effect on
+    the code).  No kernel of the library may spill a vector register (a spilled VGPR is a scratch round trip in a loop that is
+    bound by dependent latencies; the cooling-schedule variants of round 2 had 111), and the production sweep kernel must
+    exist in all its variants: {eta in LDS, eta window} x {constant, cooling schedule} x {two steps per pass with more than
+    32 blocks, two with up to 32, four with up to 32, four with up to 16, eight with up to 8}."""
+    import json
+    build = importlib.import_module("bipartitesbm-mcmc_amd.build")
+    usage = json.load(open(build.RESOURCES))
+    sweep = {k: v for k, v in usage.items() if "sweep_fast_kernel" in k}
+    assert len(sweep) == 20, sorted(sweep)
+    assert len(usage) >= 40
+    spilled = {k: v["VGPRs Spill"] for k, v in usage.items() if v.get("VGPRs Spill", 0) != 0}
+    assert not spilled, spilled
+    assert all(v["VGPRs"] <= 256 and v["Occupancy [waves/SIMD]"] >= 2 for v in sweep.values())
