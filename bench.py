@@ -63,8 +63,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spinup", type=int, default=2,
-                    help="throw-away sweeps before the warm-up; up to 6 more while launch times still settle")
+    ap.add_argument("--spinup", type=int, default=4,
+                    help="throw-away sweeps before the warm-up (four: the library launches every pass depth twice before it "
+                         "trusts a measurement); up to 6 more while launch times still settle")
     ap.add_argument("--chains", type=int, default=1024, help="chains per GPU")
     ap.add_argument("--na", type=int, default=500_000)
     ap.add_argument("--nb", type=int, default=500_000)

@@ -240,8 +240,12 @@ struct bisbm_engine {
     uint32_t last_pass_steps = 0;  // steps per pass of the last sweep launch (1, 2, 4, 8)
     // production kernel, both block counts <= 16: which depth of pass (1 / 2 / 3 = two / four / eight steps) runs how fast
     // HERE (updates per ms of the launches so far, 0 = not tried yet), and how many launches ago another one was tried
+    // measured speed (updates per ms) of the pass depths: the last two launches of each depth with their accepted fractions
+    // ([d][0]: the latest), how many launches measured it since the partition was put in place, and the figure they stand for
+    double pass_sample[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    double pass_sample_acc[4][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}};
+    uint32_t pass_n[4] = {0, 0, 0, 0};
     double pass_speed[4] = {0, 0, 0, 0};
-    double pass_acc[4] = {-1, -1, -1, -1};  // accepted fraction of the launch that last measured the depth
     double last_acc = -1;                    // accepted fraction of the last launch (any depth)
     uint32_t pass_launches = 0;
     bool pass_up = false;
@@ -328,6 +332,15 @@ void mt_seed_host(uint32_t* mt, uint64_t seed) {  // std::mt19937(seed): seed mo
     for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
 }
 
+void forget_pass_speeds(bisbm_engine* h) {
+    for (int d = 0; d < 4; ++d) {
+        h->pass_sample[d][0] = h->pass_sample[d][1] = h->pass_speed[d] = 0;
+        h->pass_sample_acc[d][0] = h->pass_sample_acc[d][1] = -1;
+        h->pass_n[d] = 0;
+    }
+    h->last_acc = -1;
+}
+
 int rebuild_state(bisbm_engine* h) {
     BuildParams bp{};
     bp.rowptr = h->d_rowptr;
@@ -349,9 +362,7 @@ int rebuild_state(bisbm_engine* h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->state_ready = true;
     // (a partition put in place from outside -- init, shuffle, merges, splits: the pass depths are measured afresh, see bisbm_anneal)
-    for (double& sp : h->pass_speed) sp = 0;
-    for (double& a : h->pass_acc) a = -1;
-    h->last_acc = -1;
+    forget_pass_speeds(h);
     h->pass_launches = 0;
     return BISBM_OK;
 }
@@ -958,9 +969,15 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
             // the last launch's (a schedule cooling down, a chain leaving its burn-in) counts as not tried -- the speed of a deep
             // pass depends on how many steps move far more than that of a two-steps pass does, so the running depth's own speed
             // does not tell.
-            auto fresh = [&](uint32_t d) {
-                return h->pass_speed[d] > 0 && !(h->last_acc >= 0 && h->pass_acc[d] >= 0 && std::fabs(h->last_acc - h->pass_acc[d]) > 0.1);
+            // And a measurement can be an outlier, always to the slow side (the first launches of a process are up to 20 % slow
+            // while the device comes up to its clocks): a depth's figure is the BEST of its last two launches in the regime, and
+            // after a new partition every depth is launched twice before any is trusted.
+            auto in_regime = [&](uint32_t d, int i) {
+                return h->pass_sample[d][i] > 0 && !(h->last_acc >= 0 && std::fabs(h->last_acc - h->pass_sample_acc[d][i]) > 0.1);
             };
+            for (uint32_t d = 1; d <= max_depth; ++d)
+                h->pass_speed[d] = std::max(in_regime(d, 0) ? h->pass_sample[d][0] : 0., in_regime(d, 1) ? h->pass_sample[d][1] : 0.);
+            auto fresh = [&](uint32_t d) { return h->pass_n[d] >= 2u && h->pass_speed[d] > 0; };
             uint32_t best = 0;
             for (uint32_t d = 1; d <= max_depth; ++d)
                 if (fresh(d) && (best == 0 || h->pass_speed[d] > h->pass_speed[best])) best = d;
@@ -1020,12 +1037,14 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
             uint64_t acc_now = 0;
             for (uint32_t c = 0; c < h->n_chains; ++c) acc_now += sc[c].last_accepted;
             const double acc_frac = (double)acc_now / (double)upd;
-            const bool same_regime = h->pass_speed[depth] > 0 && h->pass_acc[depth] >= 0 && std::fabs(acc_frac - h->pass_acc[depth]) <= 0.1;
-            h->pass_speed[depth] = same_regime ? 0.5 * (h->pass_speed[depth] + speed) : speed;
-            h->pass_acc[depth] = h->last_acc = acc_frac;
+            h->pass_sample[depth][1] = h->pass_sample[depth][0];
+            h->pass_sample_acc[depth][1] = h->pass_sample_acc[depth][0];
+            h->pass_sample[depth][0] = speed;
+            h->pass_sample_acc[depth][0] = h->last_acc = acc_frac;
+            h->pass_n[depth] += 1;
             if (getenv("BISBM_PASS_LOG"))
-                fprintf(stderr, "[bisbm passes] depth %u: %.3e updates/ms (two %.3e, four %.3e, eight %.3e)\n", depth, speed, h->pass_speed[1],
-                        h->pass_speed[2], h->pass_speed[3]);
+                fprintf(stderr, "[bisbm passes] depth %u: %.3e updates/ms, accepted %.3f (before the launch: two %.3e, four %.3e, eight %.3e)\n", depth, speed,
+                        acc_frac, h->pass_speed[1], h->pass_speed[2], h->pass_speed[3]);
         }
         if (segmented && fast && all_stopped) {  // every chain has returned (:96-98)
             if (next_slice.valid()) next_slice.wait();
@@ -2153,7 +2172,7 @@ bisbm_engine* new_group(bisbm_engine* root, uint32_t ka, uint32_t kb, uint32_t c
     g->wide = g->K > 256;
     g->epsilon = root->epsilon, g->rng_mode = root->rng_mode, g->seed = root->seed, g->gen_seed = root->gen_seed;
     g->label_stride = root->label_stride;
-    for (int d = 0; d < 4; ++d) g->pass_speed[d] = 0, g->pass_acc[d] = -1;  // (another shape: measured afresh)
+    forget_pass_speeds(g);  // (another shape: measured afresh)
     g->d_rowptr = root->d_rowptr, g->d_col = root->d_col, g->d_lgamma = root->d_lgamma, g->d_logtab = root->d_logtab, g->d_q = root->d_q;
     g->tab = root->tab, g->q_stride = root->q_stride, g->ent_deg = root->ent_deg, g->ent_multi = root->ent_multi;
     g->deg_count = root->deg_count;

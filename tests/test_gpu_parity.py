@@ -454,10 +454,10 @@ def test_last_pass_steps_reports_the_kind_of_pass_and_a_new_partition_is_measure
     for start in (g.shuffle_bisbm, g.init_bisbm):
         start()
         tried = []
-        for _ in range(2):
+        for _ in range(4):  # (every depth twice before a measurement is trusted; the deepest first on a graph of this size)
             mh.anneal(g, "constant", [1.0], na + nb, BIG)
             tried.append(g.last_pass_steps())
-        assert sorted(tried) == [2, 4], tried
+        assert tried == [4, 4, 2, 2], tried
 
 
 @pytest.mark.parametrize("roles", ["claims", "1", "2"])
