@@ -1209,13 +1209,15 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const unsigned long long hit = __builtin_amdgcn_ballot_w64((uint32_t)scan > prop);
                     const uint32_t field = (uint32_t)(hit >> (row << 4)) & 0xffffu;
                     const uint32_t s_loc = min((uint32_t)__builtin_ctz(field | 0x10000u), last_own);
-                    const bool valid = row < nst;
-                    const bool self = s_loc == r_loc;
-                    const bool live = nn_r != 1;  // (:467-471: a block is never emptied)
-                    const bool warm = CT ? true : (((zeroT_mask >> qs) & 1ull) == 0ull);  // T = 0: r == s is not accepted (:49-50)
+                    // (masks combined on the scalar side: one compare per ballot, no boolean round trips through the vector unit)
+                    const unsigned long long m_valid = nst >= 4u ? ~0ull : ((1ull << (16u * nst)) - 1ull);  // lanes of the steps that exist
+                    const unsigned long long m_live = __builtin_amdgcn_ballot_w64(nn_r != 1);  // (:467-471: a block is never emptied)
+                    const unsigned long long m_self = __builtin_amdgcn_ballot_w64(s_loc == r_loc);
+                    // T = 0: r == s is not accepted, and dS < 0 decides the others (:49-50)
+                    const unsigned long long m_warm = CT ? ~0ull : ~__builtin_amdgcn_ballot_w64(((zeroT_mask >> qs) & 1ull) != 0ull);
                     constexpr unsigned long long kRowRep = 0x8000800080008000ull;  // one lane per row (its last)
-                    const unsigned long long b_can = __builtin_amdgcn_ballot_w64(valid && live && !self) & kRowRep;
-                    const unsigned long long b_selfok = __builtin_amdgcn_ballot_w64(valid && live && self && warm) & kRowRep;
+                    const unsigned long long b_can = m_valid & m_live & ~m_self & kRowRep;
+                    const unsigned long long b_selfok = m_valid & m_live & m_self & m_warm & kRowRep;
                     if (b_can == 0ull) {  // every step of the pass is an r == s (or a vetoed one): nothing changes (:109-112)
                         acc_chunk += (uint32_t)__builtin_popcountll(b_selfok);
                         if constexpr (TM)
@@ -1273,8 +1275,12 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double z = -dS * invT;
                     const double est = accu1 * exp2_filter(z * c_l2e);
                     const double lhs = u_acc * accu0;
-                    unsigned long long b_acc = __builtin_amdgcn_ballot_w64(warm ? lhs < est : dS < 0.);  // T = 0: dS < 0 decides (:49-50)
-                    const unsigned long long b_far = __builtin_amdgcn_ballot_w64(!warm || fabs(lhs - est) > c_tol * est);
+                    unsigned long long b_acc = __builtin_amdgcn_ballot_w64(lhs < est);
+                    unsigned long long b_far = __builtin_amdgcn_ballot_w64(fabs(lhs - est) > c_tol * est);
+                    if (!CT) {  // steps at T = 0: dS < 0 decides (:49-50); nothing to be close to
+                        b_acc = (b_acc & m_warm) | (__builtin_amdgcn_ballot_w64(dS < 0.) & ~m_warm);
+                        b_far |= ~m_warm;
+                    }
                     if (__builtin_expect((~b_far & b_can) != 0ull, 0)) {  // a verdict too close to call
                         const unsigned long long exact = __builtin_amdgcn_ballot_w64(lhs < accu1 * exp(z));
                         b_acc = (b_acc & b_far) | (exact & ~b_far);
@@ -1284,7 +1290,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         const unsigned long long x = b >> 15;
                         return (uint32_t)(x | (x >> 15) | (x >> 30) | (x >> 45)) & 0xfu;
                     };
-                    const uint32_t can4 = rows4(b_can), mv4 = can4 & rows4(b_acc & kRowRep), selfok4 = rows4(b_selfok);
+                    const uint32_t mv4 = rows4(b_can & b_acc), selfok4 = rows4(b_selfok);
                     // commit_j: steps 0..j all stand.  moved bits of committed steps only.
                     uint32_t moved = mv4 & 1u, commit = 1u;
                     {
@@ -1303,11 +1309,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     acc_chunk += (uint32_t)__builtin_popcount(moved | (commit & selfok4));
                     if ((TM ? (moved | (commit & selfok4)) : moved) != 0u) {
                         // ---- apply_mcmc_moves, blockmodel.cc:461-503, for the steps that move: their rows of m differ ----
-                        unsigned long long movers = 0ull;
-                        if (moved & 1u) movers |= 0x000000000000ffffull;
-                        if (moved & 2u) movers |= 0x00000000ffff0000ull;
-                        if (moved & 4u) movers |= 0x0000ffff00000000ull;
-                        if (moved & 8u) movers |= 0xffff000000000000ull;
+                        const unsigned long long movers = __builtin_amdgcn_ballot_w64(((moved >> row) & 1u) != 0u);  // all lanes of every mover's row
                         wfence();
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & lanes_koth)) {  // k == 0: rewrites the same values
                             mq[a_rt] = m_rt_raw - k;
@@ -1388,13 +1390,15 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const unsigned long long hit1 = __builtin_amdgcn_ballot_w64((uint32_t)scan1 > prop);
                     const uint32_t field = ((uint32_t)(hit0 >> (row << 4)) & 0xffffu) | ((uint32_t)(hit1 >> (row << 4)) << 16);
                     const uint32_t s_loc = min((uint32_t)__builtin_ctz(field | 0x80000000u), last_own);
-                    const bool valid = row < nst;
-                    const bool self = s_loc == r_loc;
-                    const bool live = nn_r != 1;  // (:467-471: a block is never emptied)
-                    const bool warm = CT ? true : (((zeroT_mask >> qs) & 1ull) == 0ull);  // T = 0: r == s is not accepted (:49-50)
+                    // (masks combined on the scalar side: one compare per ballot, no boolean round trips through the vector unit)
+                    const unsigned long long m_valid = nst >= 4u ? ~0ull : ((1ull << (16u * nst)) - 1ull);  // lanes of the steps that exist
+                    const unsigned long long m_live = __builtin_amdgcn_ballot_w64(nn_r != 1);  // (:467-471: a block is never emptied)
+                    const unsigned long long m_self = __builtin_amdgcn_ballot_w64(s_loc == r_loc);
+                    // T = 0: r == s is not accepted, and dS < 0 decides the others (:49-50)
+                    const unsigned long long m_warm = CT ? ~0ull : ~__builtin_amdgcn_ballot_w64(((zeroT_mask >> qs) & 1ull) != 0ull);
                     constexpr unsigned long long kRowRep = 0x8000800080008000ull;  // one lane per row (its last)
-                    const unsigned long long b_can = __builtin_amdgcn_ballot_w64(valid && live && !self) & kRowRep;
-                    const unsigned long long b_selfok = __builtin_amdgcn_ballot_w64(valid && live && self && warm) & kRowRep;
+                    const unsigned long long b_can = m_valid & m_live & ~m_self & kRowRep;
+                    const unsigned long long b_selfok = m_valid & m_live & m_self & m_warm & kRowRep;
                     if (b_can == 0ull) {  // every step of the pass is an r == s (or a vetoed one): nothing changes (:109-112)
                         acc_chunk += (uint32_t)__builtin_popcountll(b_selfok);
                         if constexpr (TM)
@@ -1457,8 +1461,12 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double z = -dS * invT;
                     const double est = accu1 * exp2_filter(z * c_l2e);
                     const double lhs = u_acc * accu0;
-                    unsigned long long b_acc = __builtin_amdgcn_ballot_w64(warm ? lhs < est : dS < 0.);  // T = 0: dS < 0 decides (:49-50)
-                    const unsigned long long b_far = __builtin_amdgcn_ballot_w64(!warm || fabs(lhs - est) > c_tol * est);
+                    unsigned long long b_acc = __builtin_amdgcn_ballot_w64(lhs < est);
+                    unsigned long long b_far = __builtin_amdgcn_ballot_w64(fabs(lhs - est) > c_tol * est);
+                    if (!CT) {  // steps at T = 0: dS < 0 decides (:49-50); nothing to be close to
+                        b_acc = (b_acc & m_warm) | (__builtin_amdgcn_ballot_w64(dS < 0.) & ~m_warm);
+                        b_far |= ~m_warm;
+                    }
                     if (__builtin_expect((~b_far & b_can) != 0ull, 0)) {  // a verdict too close to call
                         const unsigned long long exact = __builtin_amdgcn_ballot_w64(lhs < accu1 * exp(z));
                         b_acc = (b_acc & b_far) | (exact & ~b_far);
@@ -1468,7 +1476,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         const unsigned long long x = b >> 15;
                         return (uint32_t)(x | (x >> 15) | (x >> 30) | (x >> 45)) & 0xfu;
                     };
-                    const uint32_t can4 = rows4(b_can), mv4 = can4 & rows4(b_acc & kRowRep), selfok4 = rows4(b_selfok);
+                    const uint32_t mv4 = rows4(b_can & b_acc), selfok4 = rows4(b_selfok);
                     uint32_t moved = mv4 & 1u, commit = 1u;
                     {
                         const uint32_t c01 = (clash_bits >> 1) & 1u, c02 = (clash_bits >> 2) & 1u, c03 = (clash_bits >> 3) & 1u;
@@ -1486,11 +1494,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     acc_chunk += (uint32_t)__builtin_popcount(moved | (commit & selfok4));
                     if ((TM ? (moved | (commit & selfok4)) : moved) != 0u) {
                         // ---- apply_mcmc_moves, blockmodel.cc:461-503, for the steps that move: their rows of m differ ----
-                        unsigned long long movers = 0ull;
-                        if (moved & 1u) movers |= 0x000000000000ffffull;
-                        if (moved & 2u) movers |= 0x00000000ffff0000ull;
-                        if (moved & 4u) movers |= 0x0000ffff00000000ull;
-                        if (moved & 8u) movers |= 0xffff000000000000ull;
+                        const unsigned long long movers = __builtin_amdgcn_ballot_w64(((moved >> row) & 1u) != 0u);  // all lanes of every mover's row
                         wfence();
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & lanes_koth32_lo)) {  // k == 0: rewrites the same values
                             mq[a_rt0] = m_rt_raw0 - k0;
@@ -1564,13 +1568,15 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const unsigned long long hit = __builtin_amdgcn_ballot_w64((uint32_t)scan > prop);
                     const uint32_t field = (uint32_t)(hit >> (grp << 3)) & 0xffu;
                     const uint32_t s_loc = min((uint32_t)__builtin_ctz(field | 0x100u), last_own);
-                    const bool valid = grp < nst;
-                    const bool self = s_loc == r_loc;
-                    const bool live = nn_r != 1;
-                    const bool warm = CT ? true : (((zeroT_mask >> qs) & 1ull) == 0ull);
+                    // (masks combined on the scalar side: one compare per ballot, no boolean round trips through the vector unit)
+                    const unsigned long long m_valid = nst >= 8u ? ~0ull : ((1ull << (8u * nst)) - 1ull);  // lanes of the steps that exist
+                    const unsigned long long m_live = __builtin_amdgcn_ballot_w64(nn_r != 1);  // (:467-471: a block is never emptied)
+                    const unsigned long long m_self = __builtin_amdgcn_ballot_w64(s_loc == r_loc);
+                    // T = 0: r == s is not accepted, and dS < 0 decides the others (:49-50)
+                    const unsigned long long m_warm = CT ? ~0ull : ~__builtin_amdgcn_ballot_w64(((zeroT_mask >> qs) & 1ull) != 0ull);
                     constexpr unsigned long long kGrpRep = 0x8080808080808080ull;  // one lane per group (its last)
-                    const unsigned long long b_can = __builtin_amdgcn_ballot_w64(valid && live && !self) & kGrpRep;
-                    const unsigned long long b_selfok = __builtin_amdgcn_ballot_w64(valid && live && self && warm) & kGrpRep;
+                    const unsigned long long b_can = m_valid & m_live & ~m_self & kGrpRep;
+                    const unsigned long long b_selfok = m_valid & m_live & m_self & m_warm & kGrpRep;
                     if (b_can == 0ull) {
                         acc_chunk += (uint32_t)__builtin_popcountll(b_selfok);
                         if constexpr (TM)
@@ -1624,15 +1630,19 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double z = -dS * invT;
                     const double est = accu1 * exp2_filter(z * c_l2e);
                     const double lhs = u_acc * accu0;
-                    unsigned long long b_acc = __builtin_amdgcn_ballot_w64(warm ? lhs < est : dS < 0.);
-                    const unsigned long long b_far = __builtin_amdgcn_ballot_w64(!warm || fabs(lhs - est) > c_tol * est);
+                    unsigned long long b_acc = __builtin_amdgcn_ballot_w64(lhs < est);
+                    unsigned long long b_far = __builtin_amdgcn_ballot_w64(fabs(lhs - est) > c_tol * est);
+                    if (!CT) {  // steps at T = 0: dS < 0 decides (:49-50); nothing to be close to
+                        b_acc = (b_acc & m_warm) | (__builtin_amdgcn_ballot_w64(dS < 0.) & ~m_warm);
+                        b_far |= ~m_warm;
+                    }
                     if (__builtin_expect((~b_far & b_can) != 0ull, 0)) {
                         const unsigned long long exact = __builtin_amdgcn_ballot_w64(lhs < accu1 * exp(z));
                         b_acc = (b_acc & b_far) | (exact & ~b_far);
                     }
                     // bits 7 / 15 / ... / 63 -> bits 0..7
                     auto groups8 = [](unsigned long long b) -> uint32_t { return (uint32_t)(((b >> 7) * 0x0102040810204080ull) >> 56) & 0xffu; };
-                    const uint32_t can8 = groups8(b_can), mv8 = can8 & groups8(b_acc & kGrpRep), selfok8 = groups8(b_selfok);
+                    const uint32_t mv8 = groups8(b_can & b_acc), selfok8 = groups8(b_selfok);
                     uint32_t moved = mv8 & 1u, commit = 1u, stands = 1u;
 #pragma unroll
                     for (uint32_t j = 1; j < 8u; ++j) {  // step j stands: it exists, every earlier one stood, no earlier mover clashes
@@ -1643,10 +1653,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     }
                     acc_chunk += (uint32_t)__builtin_popcount(moved | (commit & selfok8));
                     if ((TM ? (moved | (commit & selfok8)) : moved) != 0u) {
-                        unsigned long long movers = 0ull;  // all eight lanes of every mover's group
-#pragma unroll
-                        for (uint32_t g = 0; g < 8u; ++g)
-                            if ((moved >> g) & 1u) movers |= 0xffull << (8u * g);
+                        const unsigned long long movers = __builtin_amdgcn_ballot_w64(((moved >> grp) & 1u) != 0u);  // all eight lanes of every mover's group
                         wfence();
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & lanes_koth)) {
                             mq[a_rt] = m_rt_raw - k;
