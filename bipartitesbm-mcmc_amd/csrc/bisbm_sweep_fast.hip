@@ -248,7 +248,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     // constants of the hot step (log_q closed form, accept filter)
     BISBM_PIN(c_l2e, 0x1.71547652b82fep+0);        // log2(e)
     double c_tol = 1e-5;                           // accept filter margin
-    if (!(Q32 && !EL && !CT)) __asm__ volatile("" : "+v"(c_tol));  // (pinned, except in the variant where registers are scarcest)
+    if (!(Q32 && !CT)) __asm__ volatile("" : "+v"(c_tol));  // (pinned, except in the variant where registers are scarcest)
     LogQConsts lqc = log_q_consts();  // log_q closed form
     if (!(Q32 && !EL))  // (held in vector registers for the whole kernel, except where registers are scarcest: built at the use there)
         __asm__ volatile("" : "+v"(lqc.nc0l2e), "+v"(lqc.c1c0), "+v"(lqc.c1), "+v"(lqc.c2c0), "+v"(lqc.lfc));
@@ -689,28 +689,29 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const int qk2 = qk < qn ? qk : qn;
                     const double nd = (double)qn, kd = (double)qk2;
                     const double k2 = kd * kd;
-                    const bool big = qn > kQNmax;
-                    const bool direct = big && k2 > c_576 * nd;
-                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!direct) == 0, 1)) {
+                    // (the tier tests as lane masks, combined on the scalar side: every lane of the wave is active in a pass)
+                    const unsigned long long m_big = __builtin_amdgcn_ballot_w64(qn > kQNmax);
+                    const unsigned long long m_direct = m_big & __builtin_amdgcn_ballot_w64(k2 > c_576 * nd);
+                    if (__builtin_expect(m_direct == ~0ull, 1)) {
                         double sq, rr;
                         sqrt_rsqrt(nd, sq, rr);
                         return log_q_closed(kd, sq, rr, logn, lqc);
                     }
-                    if (__builtin_amdgcn_ballot_w64(big) == 0) return log_q_table(tab, qn, qk2);  // small graphs (int_part.hh:27-37)
-                    const bool ge13 = big && k2 >= c_169 * nd;
-                    const bool ge8 = big && k2 >= ldexp(nd, 6);
-                    if (__builtin_amdgcn_ballot_w64(MID ? !ge8 : !ge13) != 0) return log_q<true>(tab, qn, qk, logn);
+                    if (m_big == 0ull) return log_q_table(tab, qn, qk2);  // small graphs (int_part.hh:27-37)
+                    const unsigned long long m_ge13 = m_big & __builtin_amdgcn_ballot_w64(k2 >= c_169 * nd);
+                    const unsigned long long m_ge8 = m_big & __builtin_amdgcn_ballot_w64(k2 >= ldexp(nd, 6));
+                    if ((MID ? m_ge8 : m_ge13) != ~0ull) return log_q<true>(tab, qn, qk, logn);
                     double sq, rr;
                     sqrt_rsqrt(nd, sq, rr);
                     double lq = 0.;
-                    if (__builtin_amdgcn_ballot_w64(ge13 && !direct) != 0) lq = log_q_closed2(kd, sq, rr, logn, lqc);
-                    if (MID && __builtin_amdgcn_ballot_w64(!ge13) != 0) {
+                    if ((m_ge13 & ~m_direct) != 0ull) lq = log_q_closed2(kd, sq, rr, logn, lqc);
+                    if (MID && m_ge13 != ~0ull) {
                         const double lq_mid = log_q_mid(kd, sq, rr, logn, lqc);
-                        lq = ge13 ? lq : lq_mid;
+                        lq = __builtin_amdgcn_inverse_ballot_w64(m_ge13) ? lq : lq_mid;
                     }
-                    if (__builtin_amdgcn_ballot_w64(direct) != 0) {
+                    if (m_direct != 0ull) {
                         const double lq_far = log_q_closed(kd, sq, rr, logn, lqc);
-                        lq = direct ? lq_far : lq;
+                        lq = __builtin_amdgcn_inverse_ballot_w64(m_direct) ? lq_far : lq;
                     }
                     return lq;
                 };
