@@ -946,8 +946,11 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     uint32_t flags_pin = flags;
                     __asm__ volatile("" : "+s"(flags_pin));
                     (void)flags_pin;
-                    int dlA = (int)min(lb ^ r_locA, 1u) - (int)min(lb ^ s_locA, 1u);  // +1 on lane s, -1 on lane r
-                    int dlB = (int)min(lb ^ r_locB, 1u) - (int)min(lb ^ s_locB, 1u);
+                    // (+1 on lane s, -1 on lane r, as bit `lane` of the two one-bit block masks: v_bfe_u32 twice and a subtraction --
+                    // against min(lb ^ r, 1) - min(lb ^ s, 1), which the compiler lowers through v_cmp / v_cndmask / v_subbrev, +1.3 % on the
+                    // bench line, same box, tools/ab.sh)
+                    int dlA = (int)__builtin_amdgcn_ubfe(1u << s_locA, lb, 1u) - (int)__builtin_amdgcn_ubfe(1u << r_locA, lb, 1u);
+                    int dlB = (int)__builtin_amdgcn_ubfe(1u << s_locB, lb, 1u) - (int)__builtin_amdgcn_ubfe(1u << r_locB, lb, 1u);
                     int dmA = __mul24((int)degA, dlA), dmB = __mul24((int)degB, dlB);
                     __asm__ volatile("" : "+v"(dlA), "+v"(dlB), "+v"(dmA), "+v"(dmB));
                     // (what apply_mcmc_moves will write, worked out while the table gathers are in flight and pinned there)
