@@ -10,11 +10,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbisbm_hip.so")
-SOURCES = ["bisbm_kernels.hip", "bisbm_sweep_fast.hip", "bisbm_runtime.hip", "bisbm_io.cpp"]
-HEADERS = ["bisbm_device.hpp", "bisbm_kernels.hpp", "bisbm_multi.hpp", os.path.join("..", "host", "bisbm.hpp"),
+# translation units of the library (csrc/): the device code (kernels + their launchers), the host side of the C ABI
+# (bisbm_engine.hpp describes which unit holds what), plain C++ for the tables and the text / CSR ingest
+SOURCES = ["bisbm_kernels.hip", "bisbm_sweep_fast.hip", "bisbm_handle.hip", "bisbm_anneal.hip", "bisbm_marginals.hip",
+           "bisbm_multi.hip", "bisbm_merge.hip", "bisbm_tables.cpp", "bisbm_io.cpp"]
+HEADERS = ["bisbm_device.hpp", "bisbm_kernels.hpp", "bisbm_engine.hpp", "bisbm_pass_policy.hpp", os.path.join("..", "host", "bisbm.hpp"),
            os.path.join("..", "host", "mcmc_main.cpp"), os.path.join("..", "..", "include", "bisbm.h"),
            os.path.join("..", "..", "include", "bisbm_io.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-pthread",
          "-Wall", "-Wno-unused-function",
          # The step loop is a tree of wave-uniform branches (scalar compares, ballots).  Left to its default the
          # backend structurizes the whole loop -- flag registers, chains of always-taken jumps and a copy of every
@@ -76,20 +79,57 @@ def _resource_usage(remarks):
     return out
 
 
+def compile_library(out, extra=(), verbose=False, jobs=None):
+    """Every translation unit to an object file (side by side: the production kernel's unit takes most of the time), then one
+    link.  Returns the compiler's remarks (stderr of all units).  `extra`: more hipcc flags (diagnostic builds, tools/)."""
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    cc = hipcc()
+    objdir = tempfile.mkdtemp(prefix="bisbm_obj_")
+    try:
+        # the production kernel's 20 variants: four units of five kernels + the dispatch (BISBM_FAST_PART, bisbm_sweep_fast.hip);
+        # a build with in-kernel stamps keeps them in one unit (its counters are one device symbol)
+        units = []
+        for src in SOURCES:
+            if src == "bisbm_sweep_fast.hip" and not any("BISBM_STAMPS" in f for f in extra):
+                units += [(src, ["-DBISBM_FAST_PART=%d" % part], "%s.part%d.o" % (src, part)) for part in range(5)]
+            else:
+                units.append((src, [], src + ".o"))
+
+        def one(unit):
+            src, defs, objname = unit
+            obj = os.path.join(objdir, objname)
+            cmd = [cc] + FLAGS + ["-Rpass-analysis=kernel-resource-usage"] + list(extra) + defs + ["-c", "-o", obj, os.path.join(CSRC, src)]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed on %s:\n%s%s" % (src, r.stdout, r.stderr))
+            return obj, r.stderr
+        with ThreadPoolExecutor(max_workers=jobs or min(len(units), os.cpu_count() or 1)) as pool:
+            done = list(pool.map(one, units))
+        tmp = out + ".tmp%d" % os.getpid()
+        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", tmp] + [o for o, _ in done]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("linking %s failed:\n%s%s" % (out, r.stdout, r.stderr))
+        os.replace(tmp, out)  # (a process that has the old library mapped keeps its inode)
+        return "".join(err for _, err in done)
+    finally:
+        shutil.rmtree(objdir, ignore_errors=True)
+
+
 def _build_locked(verbose):
     import json
     extra = os.environ.get("BISBM_EXTRA_HIPCC_FLAGS", "").split()  # diagnostic builds (e.g. -DBISBM_ABLATE=1)
-    cmd = [hipcc()] + FLAGS + ["-Rpass-analysis=kernel-resource-usage"] + extra + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
-    usage = _resource_usage(r.stderr)
+    remarks = compile_library(LIB, extra, verbose)
+    usage = _resource_usage(remarks)
     with open(RESOURCES, "w") as fh:
         json.dump(usage, fh, indent=1, sort_keys=True)
     if verbose:
-        rest = "\n".join(l for l in r.stderr.splitlines() if "kernel-resource-usage" not in l and not l.lstrip().startswith(("|", "1")))
+        rest = "\n".join(l for l in remarks.splitlines() if "kernel-resource-usage" not in l and not l.lstrip().startswith(("|", "1")))
         if rest.strip():
             print(rest, file=sys.stderr)
         print("%d kernels; vector registers spilled: %d" % (len(usage), sum(k.get("VGPRs Spill", 0) for k in usage.values())), file=sys.stderr)
@@ -114,4 +154,11 @@ def build_cli(verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    # python build.py [--force]                      the product library (+ bin/mcmc)
+    # python build.py --variant OUT.so [flags ...]   a diagnostic build beside it (tools/build_variant.sh)
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        compile_library(os.path.abspath(sys.argv[i + 1]), sys.argv[i + 2:], verbose=False)
+        print(sys.argv[i + 1])
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -1,5 +1,5 @@
 // bisbm_kernels.hpp -- kernel parameter blocks and launcher prototypes shared by
-// bisbm_kernels.hip (device) and bisbm_runtime.hip (host side of the C ABI).
+// bisbm_kernels.hip, bisbm_sweep_fast.hip (device) and the host side of the C ABI (bisbm_engine.hpp lists its units).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -22,7 +22,7 @@ struct ChainScalars {
     uint32_t gen_idx;
     uint32_t merge_epoch;  // Philox counter: proposal rounds of agg_merge so far
     // where the last production sweep launch ran this chain: HW_ID of the stepping and of the feeder wave, XCC_ID
-    // (diagnostic, see BISBM_PLACEMENT_LOG in bisbm_runtime.hip)
+    // (diagnostic, see BISBM_PLACEMENT_LOG in bisbm_anneal.hip)
     uint32_t hw_id[2];
     uint32_t xcc_id;
     uint32_t split_epoch;  // Philox counter: agg_split calls so far

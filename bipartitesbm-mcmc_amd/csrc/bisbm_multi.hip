@@ -1,5 +1,4 @@
-// bisbm_multi.hpp -- several devices behind one handle (bisbm_create_multi): included once by bisbm_runtime.hip, after the
-// definition of bisbm_engine.
+// bisbm_multi.hip -- several devices behind one handle (bisbm_create_multi).
 //
 // SURVEY 8(e) / BASELINE north_star: chains are independent, so they shard over the GPUs of a node as contiguous chain
 // ranges -- graph and tables replicated per device, Philox streams keyed by the GLOBAL chain id, no exchange during
@@ -11,10 +10,14 @@
 // twice -- the one-GPU rehearsal of `--devices 0,0` --, the library missing, BISBM_POOL=p2p) the same exchange runs as
 // peer copies (hipMemcpyPeerAsync of every other device's slice to the owner of the node range + an add kernel): on the fully
 // connected xGMI topology that is the same traffic pattern, one slice per link.
-#pragma once
-
+//
+// Reference lines cited as <file>:<line> relative to /root/reference/src.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+
+#include "bisbm_engine.hpp"
+
+using namespace bisbm;
 
 namespace {
 
@@ -62,49 +65,30 @@ struct DevicePool {
     std::vector<uint32_t*> d_red, d_stage;
     std::vector<uint16_t*> d_lab, d_all;
     uint64_t per = 0;      // nodes per device range (the last ranges may reach past n: those rows are zero)
-    uint32_t kmax_cap = 0;  // columns the slices are allocated for
+    uint32_t kmax_cap = 0;  // columns the slices are allocated for (0: nothing usable allocated)
+    uint32_t peer_direct = 0;  // peer-copy path: ordered device pairs with direct peer access enabled
 };
+
+namespace bisbm {
 
 namespace {
 
-uint32_t dev_of_chain(const bisbm_engine* h, uint32_t chain, uint32_t* local) {
-    uint32_t i = 0;
-    while (i + 1 < h->devs.size() && chain >= h->dev_first[i + 1]) ++i;
-    *local = chain - h->dev_first[i];
-    return i;
-}
-
-// fn(engine of device i, i) on one host thread per device; the first failing device's code and message win
-template <class F>
-int on_devices(bisbm_engine* h, F&& fn) {
-    const size_t nd = h->devs.size();
-    std::vector<int> rcs(nd, BISBM_OK);
-    if (nd == 1) {
-        rcs[0] = fn(h->devs[0], (size_t)0);
-    } else {
-        std::vector<std::thread> th;
-        for (size_t i = 0; i < nd; ++i)
-            th.emplace_back([&, i] {
-                try {
-                    rcs[i] = fn(h->devs[i], i);
-                } catch (...) {
-                    rcs[i] = BISBM_ERR_STATE;
-                    h->devs[i]->err = "out of host memory";
-                }
-            });
-        for (auto& t : th) t.join();
+// the calling thread's current device, put back when the call returns (the pooling calls visit every device of the handle on
+// the caller's thread; a torch caller's later "current device" allocations must not move with them)
+struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard() {
+        if (hipGetDevice(&saved) != hipSuccess) saved = -1;
     }
-    for (size_t i = 0; i < nd; ++i)
-        if (rcs[i]) {
-            h->err = "device " + std::to_string(h->devs[i]->device) + ": " + h->devs[i]->err;
-            return rcs[i];
-        }
-    return BISBM_OK;
-}
+    ~DeviceGuard() {
+        if (saved >= 0) (void)hipSetDevice(saved);
+    }
+};
 
 void pool_free(bisbm_engine* h) {
     DevicePool* P = h->pool;
     if (!P) return;
+    DeviceGuard guard;
     for (size_t i = 0; i < h->devs.size(); ++i) {
         (void)hipSetDevice(h->devs[i]->device);
         if (i < P->comms.size() && P->comms[i]) (void)rccl_api().CommDestroy(P->comms[i]);
@@ -114,6 +98,26 @@ void pool_free(bisbm_engine* h) {
     }
     delete P;
     h->pool = nullptr;
+}
+
+// Peer-copy path: device i reads its node range out of every other device's histogram.  Without peer access enabled
+// hipMemcpyPeerAsync stages through host memory; with it the copy goes over the xGMI link between the two devices.  (Asked for
+// once per ordered pair; "already enabled" is fine; a pair that cannot have it keeps the staged copy, which is still correct.)
+void enable_peer_access(bisbm_engine* h, DevicePool* P) {
+    const size_t nd = h->devs.size();
+    P->peer_direct = 0;
+    for (size_t i = 0; i < nd; ++i) {
+        if (hipSetDevice(h->devs[i]->device) != hipSuccess) continue;
+        for (size_t j = 0; j < nd; ++j) {
+            const int a = h->devs[i]->device, b = h->devs[j]->device;
+            if (a == b) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) continue;
+            const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+            if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) P->peer_direct += 1;
+            (void)hipGetLastError();  // ("already enabled" stays behind as the thread's last error otherwise)
+        }
+    }
 }
 
 int pool_prepare(bisbm_engine* h, uint32_t kmax) {
@@ -142,35 +146,45 @@ int pool_prepare(bisbm_engine* h, uint32_t kmax) {
                 P->comms.clear();
             }
         }
-        if (!P->why_not_rccl.empty() && getenv("BISBM_POOL_LOG"))
-            fprintf(stderr, "[bisbm pool] peer-copy path (%s)\n", P->why_not_rccl.c_str());
+        if (P->comms.empty()) enable_peer_access(h, P);
+        if (getenv("BISBM_POOL_LOG")) {
+            if (P->comms.empty())
+                fprintf(stderr, "[bisbm pool] peer-copy path (%s); direct peer access on %u of %zu device pairs\n", P->why_not_rccl.c_str(),
+                        P->peer_direct, nd * (nd - 1));
+            else
+                fprintf(stderr, "[bisbm pool] RCCL path: %zu communicator(s) in this process (ncclCommInitAll)\n", nd);
+        }
     }
     DevicePool* P = h->pool;
     if (P->kmax_cap >= kmax) return BISBM_OK;
+    // (re)allocation: nothing of the old size counts any more from here on -- a failure part-way leaves kmax_cap = 0, so the
+    // next call starts over instead of handing half-made buffers to the collectives
+    P->kmax_cap = 0;
+    auto release = [&](auto& vec) {
+        for (size_t i = 0; i < vec.size(); ++i)
+            if (vec[i]) {
+                (void)hipSetDevice(h->devs[i]->device);
+                (void)hipFree(vec[i]);
+                vec[i] = nullptr;
+            }
+        vec.assign(nd, nullptr);
+    };
+    release(P->d_red);
+    release(P->d_stage);
+    release(P->d_lab);
+    release(P->d_all);
     for (size_t i = 0; i < nd; ++i) {
         HIPCHK(h, hipSetDevice(h->devs[i]->device));
-        for (void* p : {(void*)(i < P->d_red.size() ? P->d_red[i] : nullptr), (void*)(i < P->d_stage.size() ? P->d_stage[i] : nullptr)})
-            if (p) (void)hipFree(p);
-    }
-    P->d_red.assign(nd, nullptr);
-    P->d_stage.assign(nd, nullptr);
-    if (P->d_lab.empty()) {
-        P->d_lab.assign(nd, nullptr);
-        P->d_all.assign(nd, nullptr);
-        for (size_t i = 0; i < nd; ++i) {
-            HIPCHK(h, hipSetDevice(h->devs[i]->device));
-            HIPCHK(h, dalloc(&P->d_lab[i], (size_t)P->per));
-            HIPCHK(h, dalloc(&P->d_all[i], (size_t)P->per * nd));
-        }
-    }
-    for (size_t i = 0; i < nd; ++i) {
-        HIPCHK(h, hipSetDevice(h->devs[i]->device));
+        HIPCHK(h, dalloc(&P->d_lab[i], (size_t)P->per));
+        HIPCHK(h, dalloc(&P->d_all[i], (size_t)P->per * nd));
         HIPCHK(h, dalloc(&P->d_red[i], (size_t)P->per * kmax));
         if (P->comms.empty()) HIPCHK(h, dalloc(&P->d_stage[i], (size_t)P->per * kmax));
     }
     P->kmax_cap = kmax;
     return BISBM_OK;
 }
+
+}  // namespace
 
 // ---- the calls of the C ABI on a container ------------------------------------------------------------------------------
 int multi_common_shape(bisbm_engine* h, uint32_t* ka, uint32_t* kb) {
@@ -217,24 +231,6 @@ int multi_marginals_get(bisbm_engine* h, uint32_t* counts_out) {
     return BISBM_OK;
 }
 
-// MAP labels from the internal histogram of one engine (no pooling): argmax kernel + copy
-int single_marginals_map(bisbm_engine* h, uint32_t* labels_out) {
-    if (!h->groups.empty() && !common_shape(h))
-        return fail(h, BISBM_ERR_STATE, "the chains of this handle have different block counts: no common marginal histogram");
-    if (!h->d_counts || h->counts_cols != std::max(h->ka, h->kb)) return fail(h, BISBM_ERR_STATE, "no marginal histogram of the present block counts yet");
-    HIPCHK(h, hipSetDevice(h->device));
-    uint16_t* d_lab = nullptr;
-    HIPCHK(h, dalloc(&d_lab, (size_t)h->n));
-    std::vector<uint16_t> lab((size_t)h->n);
-    hipError_t e = launch_marginal_map(h->d_counts, (uint32_t)h->n, h->counts_cols, 0, (uint32_t)h->n, (uint32_t)h->na, h->ka, d_lab, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(lab.data(), d_lab, sizeof(uint16_t) * h->n, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(d_lab);
-    if (e != hipSuccess) return fail(h, BISBM_ERR_HIP, "marginal MAP labels: %s", hipGetErrorString(e));
-    for (uint64_t v = 0; v < h->n; ++v) labels_out[v] = lab[v];
-    return BISBM_OK;
-}
-
 int multi_marginals_map(bisbm_engine* h, uint32_t* labels_out) {
     uint32_t ka, kb;
     if (int rc = multi_common_shape(h, &ka, &kb)) return rc;
@@ -242,32 +238,39 @@ int multi_marginals_map(bisbm_engine* h, uint32_t* labels_out) {
     const size_t nd = h->devs.size();
     for (bisbm_engine* d : h->devs)
         if (!d->d_counts || d->counts_cols != kmax) return fail(h, BISBM_ERR_STATE, "no marginal histogram of the present block counts yet");
+    DeviceGuard guard;
     if (int rc = pool_prepare(h, kmax)) return rc;
     DevicePool* P = h->pool;
     const uint64_t per = P->per;
     const size_t slice = (size_t)per * kmax;
     if (!P->comms.empty()) {
         // reduce-scatter by node range, argmax on the owner, all-gather of the labels: one group call each, every
-        // device on its own stream
+        // device on its own stream.  A group that has been opened is always closed, whatever happens inside it -- an open
+        // group would swallow every later RCCL call of the process.
         RcclApi& R = rccl_api();
+        hipError_t he = hipSuccess;
         ncclResult_t r = R.GroupStart();
-        for (size_t i = 0; i < nd && r == ncclSuccess; ++i) {
-            HIPCHK(h, hipSetDevice(h->devs[i]->device));
-            r = R.ReduceScatter(h->devs[i]->d_counts, P->d_red[i], slice, ncclUint32, ncclSum, P->comms[i], h->devs[i]->stream);
+        if (r != ncclSuccess) return fail(h, BISBM_ERR_HIP, "ncclGroupStart: %s", R.GetErrorString(r));
+        for (size_t i = 0; i < nd && r == ncclSuccess && he == hipSuccess; ++i) {
+            he = hipSetDevice(h->devs[i]->device);
+            if (he == hipSuccess) r = R.ReduceScatter(h->devs[i]->d_counts, P->d_red[i], slice, ncclUint32, ncclSum, P->comms[i], h->devs[i]->stream);
         }
-        const ncclResult_t r2 = R.GroupEnd();
-        if (r != ncclSuccess || r2 != ncclSuccess) return fail(h, BISBM_ERR_HIP, "ncclReduceScatter: %s", R.GetErrorString(r != ncclSuccess ? r : r2));
+        ncclResult_t re = R.GroupEnd();
+        if (he != hipSuccess) return fail(h, BISBM_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(he));
+        if (r != ncclSuccess || re != ncclSuccess) return fail(h, BISBM_ERR_HIP, "ncclReduceScatter: %s", R.GetErrorString(r != ncclSuccess ? r : re));
         for (size_t i = 0; i < nd; ++i) {
             HIPCHK(h, hipSetDevice(h->devs[i]->device));
             HIPCHK(h, launch_marginal_map(P->d_red[i], (uint32_t)per, kmax, (uint32_t)(i * per), (uint32_t)h->n, (uint32_t)h->na, ka, P->d_lab[i], h->devs[i]->stream));
         }
         r = R.GroupStart();
-        for (size_t i = 0; i < nd && r == ncclSuccess; ++i) {
-            HIPCHK(h, hipSetDevice(h->devs[i]->device));
-            r = R.AllGather(P->d_lab[i], P->d_all[i], (size_t)per * sizeof(uint16_t), ncclUint8, P->comms[i], h->devs[i]->stream);
+        if (r != ncclSuccess) return fail(h, BISBM_ERR_HIP, "ncclGroupStart: %s", R.GetErrorString(r));
+        for (size_t i = 0; i < nd && r == ncclSuccess && he == hipSuccess; ++i) {
+            he = hipSetDevice(h->devs[i]->device);
+            if (he == hipSuccess) r = R.AllGather(P->d_lab[i], P->d_all[i], (size_t)per * sizeof(uint16_t), ncclUint8, P->comms[i], h->devs[i]->stream);
         }
-        const ncclResult_t r3 = R.GroupEnd();
-        if (r != ncclSuccess || r3 != ncclSuccess) return fail(h, BISBM_ERR_HIP, "ncclAllGather: %s", R.GetErrorString(r != ncclSuccess ? r : r3));
+        re = R.GroupEnd();
+        if (he != hipSuccess) return fail(h, BISBM_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(he));
+        if (r != ncclSuccess || re != ncclSuccess) return fail(h, BISBM_ERR_HIP, "ncclAllGather: %s", R.GetErrorString(r != ncclSuccess ? r : re));
         std::vector<uint16_t> lab((size_t)per * nd);
         HIPCHK(h, hipSetDevice(h->devs[0]->device));
         HIPCHK(h, hipMemcpyAsync(lab.data(), P->d_all[0], sizeof(uint16_t) * lab.size(), hipMemcpyDeviceToHost, h->devs[0]->stream));
@@ -300,6 +303,7 @@ int multi_marginals_map(bisbm_engine* h, uint32_t* labels_out) {
 }
 
 void multi_free(bisbm_engine* h) {
+    DeviceGuard guard;
     pool_free(h);
     for (bisbm_engine* d : h->devs) {
         free_all(d);
@@ -308,4 +312,76 @@ void multi_free(bisbm_engine* h) {
     h->devs.clear();
 }
 
-}  // namespace
+}  // namespace bisbm
+
+extern "C" {
+
+int bisbm_create_multi(bisbm_handle* out, uint64_t n, uint64_t na, uint64_t nb, const uint64_t* rowptr, const uint32_t* col,
+                       uint32_t ka, uint32_t kb, double epsilon, uint32_t n_chains, uint32_t first_chain_id, const int* devices,
+                       int n_devices, int rng_mode, uint64_t seed, uint64_t gen_seed) {
+    if (!out) return fail(nullptr, BISBM_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!devices || n_devices < 1) return fail(nullptr, BISBM_ERR_INVALID_ARG, "devices is NULL or empty");
+    if ((uint32_t)n_devices > n_chains) return fail(nullptr, BISBM_ERR_INVALID_ARG, "%d devices for %u chains: every device needs at least one chain", n_devices, n_chains);
+    std::unique_ptr<bisbm_engine> hp(new bisbm_engine());
+    bisbm_engine* h = hp.get();
+    const size_t nd = (size_t)n_devices;
+    h->device = devices[0];
+    h->n = n, h->na = na, h->nb = nb, h->ka = ka, h->kb = kb, h->K = ka + kb;
+    h->n_chains = n_chains, h->first_chain_id = first_chain_id, h->epsilon = epsilon, h->rng_mode = rng_mode, h->seed = seed, h->gen_seed = gen_seed;
+    h->counts_rows = (n + nd - 1) / nd * nd;  // node ranges of equal size for the reduce-scatter (rows past n stay zero)
+    // contiguous chain ranges, the first n_chains % n_devices devices one chain more (the split bench.py and
+    // distributed.shard_chains use)
+    h->devs.assign(nd, nullptr);
+    h->dev_first.assign(nd + 1, 0);
+    for (size_t i = 0; i < nd; ++i) h->dev_first[i + 1] = h->dev_first[i] + n_chains / (uint32_t)nd + (i < n_chains % nd ? 1u : 0u);
+    // the devices are set up side by side (graph upload, table upload); the host tables are built once and shared
+    std::vector<int> rcs(nd, BISBM_OK);
+    std::vector<std::string> errs(nd);
+    std::mutex err_mu;
+    {
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < nd; ++i)
+            th.emplace_back([&, i] {
+                bisbm_handle d = nullptr;
+                rcs[i] = bisbm_create(&d, n, na, nb, rowptr, col, ka, kb, epsilon, h->dev_first[i + 1] - h->dev_first[i],
+                                      first_chain_id + h->dev_first[i], devices[i], rng_mode, seed, gen_seed);
+                if (rcs[i]) {
+                    std::lock_guard<std::mutex> lk(err_mu);  // (the message of a failed create is a process-wide string)
+                    errs[i] = g_create_error;
+                }
+                h->devs[i] = d;
+            });
+        for (auto& t : th) t.join();
+    }
+    for (size_t i = 0; i < nd; ++i)
+        if (rcs[i]) {
+            const int rc = rcs[i];
+            const std::string msg = "device " + std::to_string(devices[i]) + ": " + errs[i];
+            for (bisbm_engine*& d : h->devs)
+                if (d) {
+                    free_all(d);
+                    delete d;
+                    d = nullptr;
+                }
+            h->devs.clear();
+            return fail(nullptr, rc, "%s", msg.c_str());
+        }
+    for (bisbm_engine* d : h->devs) d->counts_rows = h->counts_rows;
+    h->num_edges = h->devs[0]->num_edges, h->nnz = h->devs[0]->nnz, h->maxdeg = h->devs[0]->maxdeg;
+    *out = hp.release();
+    return BISBM_OK;
+}
+
+int bisbm_device_count(bisbm_handle h, int* n_devices, int* devices, uint32_t* first_chain) {
+    if (!h) return BISBM_ERR_INVALID_ARG;
+    const size_t nd = h->devs.empty() ? 1 : h->devs.size();
+    if (n_devices) *n_devices = (int)nd;
+    for (size_t i = 0; i < nd; ++i) {
+        if (devices) devices[i] = h->devs.empty() ? h->device : h->devs[i]->device;
+        if (first_chain) first_chain[i] = h->devs.empty() ? 0u : h->dev_first[i];
+    }
+    return BISBM_OK;
+}
+
+}  // extern "C"

@@ -1833,16 +1833,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     }
 }
 
-size_t sweep_fast_lds_bytes(uint32_t ka, uint32_t kb, uint32_t maxdeg, bool eta_in_lds, uint32_t eta_window) {
-    const uint32_t K = ka + kb, D = maxdeg + 1, S = kb | 1u;
-    const size_t dwords = (size_t)ka * S + (eta_in_lds ? (size_t)K * D : (size_t)std::max(ka, kb) * eta_window) +
-                          2 * (size_t)kWave * (kHistStride / 4) + 2 * (size_t)kHandWords * kWave + kWave + 4 + 10 + 16 + 64 + 128;
-    // the step reads m[.][lane] for all 64 lanes whatever ka, kb are (idle lanes are masked after the read):
-    // dword index <= 63 * S + 63 must be inside the allocation
-    const size_t reach = 63 * (size_t)S + 64;
-    return ((dwords > reach ? dwords : reach) * 4 + 15) & ~(size_t)15;
-}
-
 template <bool EL, bool CT, bool K32, bool K16, bool K8, bool Q32 = false>
 static hipError_t launch_fast_variant3(const SweepParams& p, size_t lds_bytes, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute((const void*)sweep_fast_kernel<EL, CT, K32, K16, K8, Q32>,
@@ -1855,13 +1845,51 @@ static hipError_t launch_fast_variant3(const SweepParams& p, size_t lds_bytes, h
 // One kernel per kind of pass (a kernel that held all of them ran out of registers): p.pass_depth, set by the host, says
 // which one a launch with few blocks takes.
 template <bool EL, bool CT>
-static hipError_t launch_fast_variant(const SweepParams& p, size_t lds_bytes, hipStream_t stream) {
+hipError_t launch_fast_variant(const SweepParams& p, size_t lds_bytes, hipStream_t stream) {
     const uint32_t depth = p.pair_steps < p.pass_depth ? p.pair_steps : p.pass_depth;  // 0 / 1 / 2 / 3: one, two, four, eight steps per pass
     if (p.ka <= 8u && p.kb <= 8u && depth >= 3u) return launch_fast_variant3<EL, CT, true, true, true>(p, lds_bytes, stream);
     if (p.ka <= 16u && p.kb <= 16u && depth >= 2u) return launch_fast_variant3<EL, CT, true, true, false>(p, lds_bytes, stream);
     if (p.ka <= 32u && p.kb <= 32u && depth >= 2u) return launch_fast_variant3<EL, CT, true, false, false, true>(p, lds_bytes, stream);
     return (p.ka <= 32u && p.kb <= 32u) ? launch_fast_variant3<EL, CT, true, false, false>(p, lds_bytes, stream)
                                         : launch_fast_variant3<EL, CT, false, false, false>(p, lds_bytes, stream);
+}
+
+// The 20 variants compile side by side: the build (build.py) compiles this file once per BISBM_FAST_PART = 0 .. 3 -- the five
+// kernels of one (EL, CT) each -- and once with BISBM_FAST_PART = 4 for the dispatch below; undefined: everything in one unit
+// (diagnostic builds with in-kernel stamps, whose counters are one device symbol).
+#ifndef BISBM_FAST_PART
+#define BISBM_FAST_PART -1
+#endif
+#define BISBM_FAST_HERE(part) (BISBM_FAST_PART == -1 || BISBM_FAST_PART == (part))
+#if BISBM_FAST_HERE(0)
+template hipError_t launch_fast_variant<false, false>(const SweepParams&, size_t, hipStream_t);
+#endif
+#if BISBM_FAST_HERE(1)
+template hipError_t launch_fast_variant<false, true>(const SweepParams&, size_t, hipStream_t);
+#endif
+#if BISBM_FAST_HERE(2)
+template hipError_t launch_fast_variant<true, false>(const SweepParams&, size_t, hipStream_t);
+#endif
+#if BISBM_FAST_HERE(3)
+template hipError_t launch_fast_variant<true, true>(const SweepParams&, size_t, hipStream_t);
+#endif
+
+#if BISBM_FAST_HERE(4)
+#if BISBM_FAST_PART == 4
+extern template hipError_t launch_fast_variant<false, false>(const SweepParams&, size_t, hipStream_t);
+extern template hipError_t launch_fast_variant<false, true>(const SweepParams&, size_t, hipStream_t);
+extern template hipError_t launch_fast_variant<true, false>(const SweepParams&, size_t, hipStream_t);
+extern template hipError_t launch_fast_variant<true, true>(const SweepParams&, size_t, hipStream_t);
+#endif
+
+size_t sweep_fast_lds_bytes(uint32_t ka, uint32_t kb, uint32_t maxdeg, bool eta_in_lds, uint32_t eta_window) {
+    const uint32_t K = ka + kb, D = maxdeg + 1, S = kb | 1u;
+    const size_t dwords = (size_t)ka * S + (eta_in_lds ? (size_t)K * D : (size_t)std::max(ka, kb) * eta_window) +
+                          2 * (size_t)kWave * (kHistStride / 4) + 2 * (size_t)kHandWords * kWave + kWave + 4 + 10 + 16 + 64 + 128;
+    // the step reads m[.][lane] for all 64 lanes whatever ka, kb are (idle lanes are masked after the read):
+    // dword index <= 63 * S + 63 must be inside the allocation
+    const size_t reach = 63 * (size_t)S + 64;
+    return ((dwords > reach ? dwords : reach) * 4 + 15) & ~(size_t)15;
 }
 
 hipError_t launch_sweep_fast(const SweepParams& p, size_t /*generic_lds_bytes*/, hipStream_t stream) {
@@ -1890,5 +1918,6 @@ hipError_t launch_sweep_fast(const SweepParams& p, size_t /*generic_lds_bytes*/,
 #endif
     return e;
 }
+#endif  // BISBM_FAST_HERE(4)
 
 }  // namespace bisbm

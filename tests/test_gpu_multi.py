@@ -103,6 +103,84 @@ def test_devices_behind_one_handle_equal_one_device(graph, devices, mode):
     many.close()
 
 
+def _pooled(rowptr, col, na, nb, ka, kb, labels, chains, capfd, **kw):
+    """shuffle, three sweeps with a sample of every chain each, a split of each type (max(KA, KB) grows: the pool's slices are
+    allocated afresh), three more samples: MAP labels after both stages, the full histogram, and what BISBM_POOL_LOG said"""
+    g = _model(rowptr, col, na, nb, ka, kb, 1.0, labels, n_chains=chains, rng="philox", seed=77, **kw)
+    g.shuffle_bisbm()
+    out = []
+    capfd.readouterr()
+    for stage in range(2):
+        g.marginals_reset()
+        for _ in range(3):
+            g.run_sweeps(1)
+            g.marginals_accumulate(None)
+        out.append((g.marginals_map().copy(), g.marginals_get().copy()))
+        if stage == 0:
+            g.agg_merge(-1, -1, 4)
+    log = capfd.readouterr().err
+    g.close()
+    return out, log
+
+
+def test_rccl_branch_runs_with_one_rank(monkeypatch, capfd):
+    """A multi-device handle over ONE distinct device takes the RCCL branch of the pooling (bisbm_multi.hip: librccl.so resolved
+    with dlopen / dlsym, ncclCommInitAll, the grouped ncclReduceScatter, the argmax kernel, the grouped ncclAllGather) -- what a
+    one-GPU box can execute of the exchange every multi-GPU node runs by default.  Its MAP labels must be the single-engine
+    handle's and the peer-copy path's (BISBM_POOL=p2p), before and after max(KA, KB) has grown."""
+    import torch
+    rowptr, col, na, nb = O.load_graph("n_1000")
+    n = na + nb
+    labels = O.contiguous_labels(na, nb, 4, 6)
+    monkeypatch.setenv("BISBM_POOL_LOG", "1")
+    monkeypatch.delenv("BISBM_POOL", raising=False)
+    before = torch.cuda.current_device()
+    plain, log_plain = _pooled(rowptr, col, na, nb, 4, 6, labels, 9, capfd, device=0)
+    rccl, log_rccl = _pooled(rowptr, col, na, nb, 4, 6, labels, 9, capfd, devices=[0])
+    assert "[bisbm pool]" not in log_plain
+    assert log_rccl.count("[bisbm pool] RCCL path: 1 communicator(s)") == 1 and "peer-copy" not in log_rccl, log_rccl
+    monkeypatch.setenv("BISBM_POOL", "p2p")
+    p2p, log_p2p = _pooled(rowptr, col, na, nb, 4, 6, labels, 9, capfd, devices=[0])
+    assert "peer-copy path (BISBM_POOL=p2p)" in log_p2p and "RCCL path" not in log_p2p
+    assert torch.cuda.current_device() == before
+    for stage, (ka, kb) in enumerate(((4, 6), (5, 7))):
+        counts = plain[stage][1]
+        assert counts.shape == (n, max(ka, kb)) and counts.sum() == 3 * 9 * n
+        want = counts.argmax(axis=1) + np.where(np.arange(n) >= na, ka, 0)
+        for got in (plain, rccl, p2p):
+            assert (got[stage][1] == counts).all()
+            assert (got[stage][0] == want).all()
+
+
+def _n_devices():
+    import torch
+    return torch.cuda.device_count()  # (counts devices without bringing the GPU up)
+
+
+@pytest.mark.skipif(_n_devices() < 2, reason="needs two distinct GPUs")
+@pytest.mark.parametrize("pool", ["rccl", "p2p"])
+def test_two_distinct_devices_pool_like_one(pool, monkeypatch, capfd):
+    """Two different ordinals behind one handle: the exchange proper -- RCCL between two ranks of this process, or peer copies
+    with peer access enabled over the xGMI link -- against a single-device handle with all the chains.  (Skipped on a one-GPU
+    box; there test_rccl_branch_runs_with_one_rank and the device-listed-twice rehearsal cover what can run.)"""
+    import torch
+    rowptr, col, na, nb = O.load_graph("n_1000")
+    n = na + nb
+    labels = O.contiguous_labels(na, nb, 4, 6)
+    monkeypatch.setenv("BISBM_POOL_LOG", "1")
+    if pool == "p2p":
+        monkeypatch.setenv("BISBM_POOL", "p2p")
+    else:
+        monkeypatch.delenv("BISBM_POOL", raising=False)
+    before = torch.cuda.current_device()
+    plain, _ = _pooled(rowptr, col, na, nb, 4, 6, labels, 9, capfd, device=0)
+    two, log = _pooled(rowptr, col, na, nb, 4, 6, labels, 9, capfd, devices=[0, 1])
+    assert ("RCCL path: 2 communicator(s)" in log) if pool == "rccl" else ("peer-copy path (BISBM_POOL=p2p)" in log), log
+    assert torch.cuda.current_device() == before  # the pooling calls visit every device and put the caller's back
+    for stage in range(2):
+        assert (two[stage][1] == plain[stage][1]).all() and (two[stage][0] == plain[stage][0]).all()
+
+
 def test_cli_devices_flag_prints_what_one_device_prints():
     """`mcmc --devices 0,0 --chains N` == `mcmc --device 0 --chains N`, byte for byte on stdout: the annealing driver (the chain
     with the lowest description length is printed) and --marginalize (the histogram pooled over the devices)."""

@@ -366,7 +366,7 @@ def test_pass_depth_is_chosen_from_timed_launches_and_never_changes_results(monk
     """With few blocks the depth of the passes (two / four / eight steps) is chosen per launch from the measured speed of the
     launches, and a long constant-temperature call runs as several launches so that the choice can follow the chain.  The
     chain does not depend on any of it: pinned depths and the free choice give bit-equal labels, rates and sums; the log shows
-    that the free run tried every depth."""
+    that the free run measured the deepest pass and its neighbour and looked at a neighbour again later."""
     rowptr, col, na, nb = O.load_graph("n_1000")
     n = na + nb
     lab = O.contiguous_labels(na, nb, 4, 6)
@@ -394,8 +394,11 @@ def test_pass_depth_is_chosen_from_timed_launches_and_never_changes_results(monk
         log = capfd.readouterr().err
         out[pin] = (rates, [g.get_memberships(c) for c in range(7)], g.get_entropy(), g.last_counts())
         if pin is None:
-            tried = {int(line.split("depth ")[1][0]) for line in log.splitlines() if line.startswith("[bisbm passes]")}
-            assert tried == {1, 2, 3}, log[-2000:]
+            ran = [int(line.split("depth ")[1][0]) for line in log.splitlines() if line.startswith("[bisbm passes]")]
+            # (bisbm_pass_policy.hpp: the deepest first on a graph of this size, then its neighbour; the shallowest only if four
+            # steps per pass beat eight; in steady state one launch in sixteen looks at a neighbour)
+            assert ran[:2] == [3, 3] and {2, 3} <= set(ran), log[-2000:]
+            assert "(a look)" in log
     monkeypatch.delenv("BISBM_PASS_LOG", raising=False)
     ref = out[None]
     for pin in ("2", "4", "8"):

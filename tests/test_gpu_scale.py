@@ -218,11 +218,14 @@ def test_deep_passes_at_full_size(k, monkeypatch):
 
 
 # ------------------------------------------------------------------ BASELINE configs[4]: per-GPU shape
-def test_config5_shape_properties():
+@pytest.mark.parametrize("chains,container", [(256, False), (1024, True)])
+def test_config5_shape_properties(chains, container, monkeypatch, capfd):
     """N_a = N_b = 2e6, E = 5e7, Ka = Kb = 64 (the K > 32 variant of the production kernel: two steps per pass with two
-    blocks per lane, a window of eta in LDS), 256 chains -- the per-GPU shape of BASELINE configs[4] at a quarter of its
-    chains: a sweep at constant T and a sweep under a cooling schedule keep the incremental state equal to a recount, block
-    sizes sum to N, and the sum of accepted dS equals the change of the full description length, in every chain."""
+    blocks per lane, a window of eta in LDS) -- the per-GPU shape of BASELINE configs[4], at a quarter of its chains on a plain
+    handle and at its full per-GPU load of 1024 chains behind a multi-device handle over this one device (`devices=[0]`: what
+    each GPU of the 8-GPU configuration runs, pooling of the marginals through RCCL included): a sweep at constant T and a
+    sweep under a cooling schedule keep the incremental state equal to a recount, block sizes sum to N, and the sum of accepted
+    dS equals the change of the full description length, in every chain."""
     na = nb = 2_000_000
     ka = kb = 64
     E = 50_000_000
@@ -230,8 +233,8 @@ def test_config5_shape_properties():
     rowptr, col = B.edge_to_adj((a, b), na + nb)
     del a, b
     labels = SYN.contiguous_labels(na, nb, ka, kb)
-    chains = 256
-    g = gpu_model(rowptr, col, na, nb, ka, kb, 1.0, labels, n_chains=chains, rng="philox", seed=5)
+    monkeypatch.setenv("BISBM_POOL_LOG", "1")
+    g = gpu_model(rowptr, col, na, nb, ka, kb, 1.0, labels, n_chains=chains, rng="philox", seed=5, **({"devices": [0]} if container else {}))
     g.shuffle_bisbm()
     s0 = g.entropy()
     rates = B.MetropolisHasting().anneal(g, "constant", [1.0], na + nb, BIG)
@@ -257,6 +260,20 @@ def test_config5_shape_properties():
         assert n_r.sum() == na + nb and m_r.sum() == 2 * E
         assert (np.bincount(lab, minlength=ka + kb) == n_r).all()
     assert all((g.get_n_r(c) == x).all() for c, x in zip(range(0, chains, 17), n_r_all))
+    if container:
+        # configs[4]'s exchange at this device's share of it: one sample of every chain into the histogram (1 GB of counters),
+        # pooled by reduce-scatter -> argmax -> all-gather through RCCL (one rank here), against numpy on the host copy
+        g.marginals_reset()
+        g.marginals_accumulate(None)
+        capfd.readouterr()
+        lab_map = g.marginals_map()
+        log = capfd.readouterr().err
+        assert "[bisbm pool] RCCL path" in log and "peer-copy" not in log, log
+        counts = g.marginals_get()
+        assert counts.shape == (na + nb, 64) and int(counts.sum()) == chains * (na + nb)
+        want = counts.argmax(axis=1) + np.where(np.arange(na + nb) >= na, ka, 0)
+        assert (lab_map == want).all()
+        del counts, want
     # chains are distinct (keyed by chain id) and reproducible: chain 7 re-run alone gives the same labels
     assert (labs[0] != labs[1]).any()
     solo = gpu_model(rowptr, col, na, nb, ka, kb, 1.0, labels, n_chains=1, rng="philox", seed=5, first_chain_id=7)
