@@ -80,6 +80,9 @@ def parse_args(argv=None):
                     help="after the timed region let the chains run on until they have done this many sweeps in all, then time "
                          "three more: the steady-state figure, measured live (150 takes ~1.5 min at the default workload)")
     ap.add_argument("--sweeps-per-step", type=int, default=1, help="sweeps of every chain per timed step (small graphs: one launch should last milliseconds)")
+    ap.add_argument("--rng", choices=["philox", "compat"], default="philox",
+                    help="compat: the mt19937-compat path (the reference's own random streams, draw order and summation order -- the "
+                         "only path that is bit-exact with the reference; a verification mode, one generic-kernel wave per chain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra legs after the timed region (equilibrated-start figure, pooling timings)")
@@ -221,17 +224,80 @@ def cpu_worker(args):
         m.anneal("constant", [1.0], extra * n, 1 << 60)
         dt += time.perf_counter() - t0
         steps += extra * n
-    print(json.dumps({"steps": steps, "seconds": dt}), flush=True)
-
-
-def cpu_baseline(n, seconds_budget=18.0, probe=None):
-    """`cores` independent single-chain processes of the oracle, one per host core, timed together (the reference is
-    single-threaded: its multi-core figure is one process per core).  value = their summed rate."""
-    cores = max(1, min(os.cpu_count() or 1, 16))
+    rss = 0
     try:
-        cores = max(1, min(cores, len(os.sched_getaffinity(0))))
-    except (AttributeError, OSError):
+        with open("/proc/self/status") as f:
+            for ln in f:
+                if ln.startswith("VmHWM"):
+                    rss = int(ln.split()[1]) * 1024
+    except OSError:
         pass
+    print(json.dumps({"steps": steps, "seconds": dt, "rss": rss}), flush=True)
+
+
+def _cpu_limits():
+    """What this process may use of the host: logical CPUs of the box, CPUs in the affinity mask, the CPU quota of the
+    control group it runs in (cgroup v2 cpu.max / v1 cfs quota; None: unlimited), and the memory still available."""
+    total = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = total
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()
+            if q != "max":
+                quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, period = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    mem = None
+    try:
+        with open("/proc/meminfo") as f:
+            for ln in f:
+                if ln.startswith("MemAvailable"):
+                    mem = int(ln.split()[1]) * 1024
+        for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+            if os.path.exists(path):
+                with open(path) as f:
+                    v = f.read().strip()
+                if v != "max" and int(v) < (1 << 60):
+                    mem = min(mem, int(v)) if mem else int(v)
+                break
+    except (OSError, ValueError):
+        pass
+    return total, affinity, quota, mem
+
+
+def _worker_rss_bytes(n, n_edges):
+    """Resident set of one oracle process at this workload (measured: 1.35 GB at N = 10^6, E = 10^7; the workers report their own, `rss_per_worker_bytes`): interpreter + numpy
+    ~0.1 GB, the generator's edge arrays and the CSR, and the oracle's state (it keeps the reference's N x K neighbour-count
+    matrix)."""
+    return int(0.15e9 + 90.0 * n_edges + 300.0 * n)
+
+
+def cpu_baseline(n, n_edges, seconds_budget=18.0, probe=None):
+    """Independent single-chain processes of the oracle, one per host core this process may use, timed together (the reference
+    is single-threaded: its multi-core figure is one process per core).  value = their summed rate.  Workers = the
+    CPUs of the affinity mask, capped by the control group's CPU quota (more runnable processes than the quota only take turns)
+    and by memory (every worker holds the graph and the oracle's state)."""
+    total, affinity, quota, mem = _cpu_limits()
+    cores = affinity
+    if quota is not None:
+        cores = min(cores, max(1, int(quota + 0.5)))
+    rss = _worker_rss_bytes(n, n_edges)
+    if mem:
+        cores = min(cores, max(1, int(0.5 * mem // rss)))
+    env_cap = os.environ.get("BISBM_BENCH_CPU_WORKERS")
+    if env_cap:
+        cores = min(cores, max(1, int(env_cap)))
+    cores = max(1, cores)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(seconds_budget)] + \
           [a for a in sys.argv[1:] if a not in ("--no-extras",)]
     procs = [subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True,
@@ -247,17 +313,24 @@ def cpu_baseline(n, seconds_budget=18.0, probe=None):
         res.append(json.loads(p.stdout.readline()))
         p.wait()
     per_core = [r["steps"] / r["seconds"] for r in res]
-    total = float(sum(per_core))
+    total_rate = float(sum(per_core))
     one = float(np.median(per_core))
-    return {"value": total, "unit": "updates/s", "cores": cores, "kind": "port",
+    pr = probe or REF_PROBE
+    return {"value": total_rate, "unit": "updates/s", "cores": cores, "kind": "port",
+            "cores_total": total, "cores_in_affinity_mask": affinity, "cgroup_cpu_quota": quota,
+            "rss_per_worker_bytes": int(max(r.get("rss", 0) for r in res)), "memory_available_bytes": mem,
             "per_core": one, "cpu": _cpu_model(),
-            "sample": "oracle/bisbm_oracle.c (mt19937-compat), %d independent 1-chain processes (one per core), %d-%d "
+            "sample": "oracle/bisbm_oracle.c (mt19937-compat), %d independent 1-chain processes (one per usable core), %d-%d "
                       "sweeps each of the same graph, anneal() wall time only, %.1f s" % (
                           cores, min(r["steps"] for r in res) // n, max(r["steps"] for r in res) // n,
                           max(r["seconds"] for r in res)),
-            "ratio_to_reference": (probe or REF_PROBE)["port_updates_per_s_same_cpu"] / (probe or REF_PROBE)["reference_updates_per_s"],
-            "reference_estimate_updates_per_s": total * (probe or REF_PROBE)["reference_updates_per_s"] / (probe or REF_PROBE)["port_updates_per_s_same_cpu"],
-            "reference_probe": probe or REF_PROBE}
+            # The reference's own binary cannot be built on this image (Boost).  What is known about it is one probe on ANOTHER
+            # CPU (the build container's Xeon): there the port ran `ratio` times faster than the reference at this workload, whose
+            # cost is cache misses into the reference's dense N x K matrix -- so the ratio need not carry over to this host.
+            "reference_on_another_cpu": {"port_over_reference_there": pr["port_updates_per_s_same_cpu"] / pr["reference_updates_per_s"],
+                                         "estimate_for_this_host_updates_per_s": total_rate * pr["reference_updates_per_s"] / pr["port_updates_per_s_same_cpu"],
+                                         "caveat": "ratio measured on another CPU (smaller L3): an estimate, not a measurement on this box",
+                                         "probe": pr}}
 
 
 # ----------------------------------------------------------------------------------------------- main
@@ -341,7 +414,7 @@ def main():
     labels = syn.contiguous_labels(na, nb, ka, kb)
     shard = pkg.ChainShard(args.chains * world, rank=rank, world_size=world)
     model = pkg.BlockModel(labels, syn.types_vector(na, nb), ka + kb, ka, kb, 1.0, (rowptr, col),
-                           n_chains=shard.n_local, rng="philox", seed=20240229, device=device_index,
+                           n_chains=shard.n_local, rng=args.rng, seed=20240229, gen_seed=20240301, device=device_index,
                            first_chain_id=shard.first_chain_id)
     if args.planted_start:
         model.set_memberships(planted)
@@ -384,10 +457,13 @@ def main():
     t0 = time.perf_counter()
     kernel_ms, updates = 0.0, 0
     pass_steps = []  # steps per pass of each timed launch (chosen per launch by the library; the chain does not depend on it)
+    launch_ms, launch_acc = [], []  # ... its kernel time and the fraction of its steps that were accepted
     for _ in range(args.steps):
         sweep()
         ms, upd = model.last_sweep_timing()
         pass_steps.append(model.last_pass_steps())
+        launch_ms.append(round(ms, 2))
+        launch_acc.append(round(float(model.last_counts()[0].sum()) / max(upd, 1), 4))
         note("timed")
         kernel_ms += ms
         updates += upd
@@ -480,7 +556,7 @@ def main():
         balg = b_alg_per_update(n, E)
         achieved = balg * per_launch_updates / avg_kernel_s / 1e9
         default_cfg = ((na, nb, E, ka, kb, args.chains) == (500_000, 500_000, 10_000_000, 32, 32, 1024) and not args.shuffle_ids
-                       and not args.planted_start and not args.edgelist and args.sweeps_per_step == 1)
+                       and not args.planted_start and not args.edgelist and args.sweeps_per_step == 1 and args.rng == "philox")
         # HBM bytes per launch and instructions per update from the PMC passes committed under profiles/ (rocprofv3
         # --pmc, separate runs of this same command); only quoted for the workload they were measured on
         traffic, traffic_src, issue, steady = None, None, None, None
@@ -521,7 +597,7 @@ def main():
         if steady_live is not None:
             steady = dict(steady or {}, live=steady_live)
         roofline = {
-            "bound": "hbm", "kernel": "sweep_fast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": "sweep_fast_kernel" if args.rng == "philox" else "sweep_kernel<mt19937-compat>", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "alg_bytes_per_update": balg, "updates_per_launch": per_launch_updates,
             "avg_launch_ms": avg_kernel_s * 1e3,
@@ -547,7 +623,8 @@ def main():
                 "workload": ("BASELINE configs[2]: " if default_cfg else (args.preset + ": ") if args.preset else "custom: ")
                 + ("edge list %s, " % os.path.basename(args.edgelist) if args.edgelist else "planted bipartite ")
                 + "N_a=%d N_b=%d E=%d Ka=%d Kb=%d, %d chains/GPU, constant T=1, eps=1, "
-                  "%s start, Philox mode%s" % (na, nb, E, ka, kb, args.chains, "planted-partition" if args.planted_start else "randomised",
+                  "%s start, %s mode%s" % (na, nb, E, ka, kb, args.chains, "planted-partition" if args.planted_start else "randomised",
+                                                       "Philox" if args.rng == "philox" else "mt19937-compat (bit-exact with the reference)",
                                                        (", node ids renumbered at random" +
                                                         (", locality reordering at ingest (%.1f s)" % reorder_s if reorder else ""))
                                                        if args.shuffle_ids else ""),
@@ -556,6 +633,9 @@ def main():
                 "spinup_sweeps_before_warmup": len(spin_ms),
                 "accepted_fraction_last_timed_sweep": accepted_frac,
                 "steps_per_pass_of_the_timed_launches": {str(k): pass_steps.count(k) for k in sorted(set(pass_steps))},
+                # every timed step in order: steps per pass the library chose for it (bisbm_pass_policy.hpp: the incumbent depth,
+                # one look at a neighbour in sixteen launches), its kernel time, its accepted fraction
+                "per_launch_steps_per_pass": pass_steps, "per_launch_ms": launch_ms, "per_launch_accepted": launch_acc,
                 "parallelism": "chains sharded, no collective in the sweep path",
                 "collective_backend": (backend if world > 1 else None), "collective_backend_note": backend_note,
             },
@@ -567,7 +647,7 @@ def main():
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             del model
-            out["cpu_baseline"] = cpu_baseline(n, probe=REF_PROBE_N1000 if args.preset == "BASELINE configs[1]" else None)
+            out["cpu_baseline"] = cpu_baseline(n, E, probe=REF_PROBE_N1000 if args.preset == "BASELINE configs[1]" else None)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

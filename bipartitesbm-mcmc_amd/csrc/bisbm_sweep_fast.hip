@@ -961,12 +961,20 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     double accu0, accu1;  // lanes 16..31: step q, lanes 48..63: step q + 1
                     butterfly_accu_rows32(a0, a1, accu0, accu1);
                     FSTAMP_STEP(4);
+#ifdef BISBM_PROBE_NOPS  // diagnostic: idle issue slots in the shadow of the table gathers (how much of their latency is still exposed?)
+#pragma unroll
+                    for (int i_ = 0; i_ < BISBM_PROBE_NOPS; ++i_) __asm__ volatile("s_nop 0");
+#endif
                     const double lq = hot_log_q(std::true_type{}, qn, qk, logn);
                     FSTAMP_STEP(5);
                     double d = (L1 + L2) - (L3 + L4);
                     d = d + tail_lg * sign_tail;
                     d = d + lq * sign_q;
                     const double dS = butterfly_rows32(d);
+#ifdef BISBM_PROBE_NOPS_TAIL  // diagnostic: the same number of idle slots on the tail, where nothing is in flight
+#pragma unroll
+                    for (int i_ = 0; i_ < BISBM_PROBE_NOPS_TAIL; ++i_) __asm__ volatile("s_nop 0");
+#endif
                     FSTAMP_STEP(6);
                     // accept (:47-61) in the lanes that hold the sums; bit 31 is step q's verdict, bit 63 step q + 1's
                     double invT = invT_const;

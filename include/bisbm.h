@@ -178,7 +178,13 @@ int bisbm_marginals_map(bisbm_handle h, uint32_t *labels_out /* n, host */);
  * the node within its block -- which is what agg_split's own pass (:554-561) uses.
  * The two-type overload changes every chain's counts by the same amounts.  The selection is
  * K-scale host work, as in the reference; ranks, cut evaluation, relabelling and the rebuild run on the device.
- * BISBM_ERR_UNSUPPORTED when a split would exceed 256 blocks, BISBM_ERR_STATE when no block can be split. */
+ * BISBM_ERR_STATE when no block can be split (asked before anything about the handle changes: a refused split leaves the
+ * labels, their width and the block state as they were); a split past 256 blocks switches the handle to two-byte labels.
+ * Several devices / several shapes behind one handle: a request that some chain cannot meet is refused before any device or
+ * group changes.  What is NOT atomic is a failure in the middle of the work (a device out of memory): the devices run side
+ * by side, so the others have merged by then -- the call returns the first failing device's code, bisbm_last_error names
+ * every device that failed, and the handle keeps serving per-chain calls (bisbm_get_ka_kb_chain tells which chains
+ * changed shape); a caller that needs all-or-nothing keeps the labels (bisbm_get_memberships) and puts them back. */
 int bisbm_agg_merge(bisbm_handle h, int diff_a, int diff_b, int nm);
 
 /* blockmodel_t::agg_merge(engine, diff, nm) (blockmodel.cc:208-271; call site mcmc_main.cc:365): diff merges over
