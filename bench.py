@@ -66,7 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--spinup", type=int, default=4,
                     help="throw-away sweeps before the warm-up (four: the library launches every pass depth twice before it "
                          "trusts a measurement); up to 6 more while launch times still settle")
-    ap.add_argument("--chains", type=int, default=1024, help="chains per GPU")
+    ap.add_argument("--chains", type=int, default=None, help="chains per GPU (default 1024; 256 for --edgelist n_1000)")
     ap.add_argument("--na", type=int, default=500_000)
     ap.add_argument("--nb", type=int, default=500_000)
     ap.add_argument("--edges", type=int, default=10_000_000)
@@ -76,9 +76,10 @@ def parse_args(argv=None):
                     help="run on this edge-list file instead of the synthetic graph (--na / --nb give the type sizes, --ka / --kb the "
                          "blocks of the contiguous initial partition); --edgelist n_1000 = the reference's shipped 1000-node data "
                          "set as BASELINE configs[1] runs it (Ka = 4, Kb = 6, 256 chains, 2000 sweeps per step)")
-    ap.add_argument("--steady-sweeps", type=int, default=0,
+    ap.add_argument("--steady-sweeps", type=int, default=None,
                     help="after the timed region let the chains run on until they have done this many sweeps in all, then time "
-                         "three more: the steady-state figure, measured live (150 takes ~1.5 min at the default workload)")
+                         "three more: the steady-state figure, measured live.  Default: 150 on the default workload with one GPU "
+                         "(~1.5 min; --no-extras skips it), 0 otherwise")
     ap.add_argument("--sweeps-per-step", type=int, default=1, help="sweeps of every chain per timed step (small graphs: one launch should last milliseconds)")
     ap.add_argument("--rng", choices=["philox", "compat"], default="philox",
                     help="compat: the mt19937-compat path (the reference's own random streams, draw order and summation order -- the "
@@ -140,12 +141,14 @@ def apply_presets(args):
         args.edgelist = os.path.join(ROOT, "tests", "golden", "bisbm-n_1000-ka_4-kb_6.edgelist")
         args.preset = "BASELINE configs[1]"
         args.na, args.nb, args.ka, args.kb = 500, 500, 4, 6
-        if args.chains == 1024:
+        if args.chains is None:
             args.chains = 256
         if args.sweeps_per_step == 1:
             args.sweeps_per_step = 2000
     else:
         args.preset = None
+    if args.chains is None:
+        args.chains = 1024
     return args
 
 
@@ -511,6 +514,10 @@ def main():
         del counts, send
 
     # the same chains further along (a marginalize run lives there, not in the burn-in the protocol's sweeps see)
+    if args.steady_sweeps is None:
+        is_default = ((na, nb, args.edges, ka, kb, args.chains) == (500_000, 500_000, 10_000_000, 32, 32, 1024) and not args.edgelist
+                      and not args.shuffle_ids and not args.planted_start and args.rng == "philox" and args.sweeps_per_step == 1)
+        args.steady_sweeps = 150 if (is_default and world == 1 and not args.no_extras) else 0
     steady_live = None
     sweeps_so_far = (len(spin_ms) + args.warmup + args.steps) * args.sweeps_per_step
     if args.steady_sweeps > sweeps_so_far:
