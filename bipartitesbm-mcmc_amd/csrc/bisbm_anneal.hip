@@ -206,6 +206,19 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
     // the table slices above); a chain that has returned (steps_await == 0 at T >= 1: after its FIRST sweep, :96-98) is skipped
     // by the later launches, and the loop below ends when every chain has.  (A constant schedule at T = 0 runs general steps
     // only: nothing to choose.)
+    // A production launch without anneal()'s early-stop bookkeeping does not keep the running sum of accepted dS (it costs every
+    // pass ~10 instructions and nobody looks at it meanwhile): the call advances the sum by the change of the block-state part of
+    // the description length instead -- evaluated before the first launch (or known from the call before) and after the last one.
+    // (BISBM_KEEP_SUM=1: every launch keeps the sum of its own dS values, for the tests that compare exactly that with the change
+    // of the description length)
+    p.keep_sum = (getenv("BISBM_KEEP_SUM") && getenv("BISBM_KEEP_SUM")[0] == '1') ? 1u : 0u;
+    const bool sum_from_entropy = fast && p.keep_sum == 0u && !sweep_fast_tracks_minimum(schedule, p.kw0, steps_await, duration_steps);
+    if (sum_from_entropy) {
+        if (!h->d_ent_prev) HIPCHK(h, dalloc(&h->d_ent_prev, h->n_chains));
+        if (!h->ent_prev_valid)
+            if (int rc = launch_block_entropy(h, h->d_ent_prev)) return rc;
+    }
+    h->ent_prev_valid = false;  // (until this call has ended the way it was meant to)
     const bool depth_segments = max_depth >= 2u && !(schedule == SCHED_CONSTANT && !(kwargs[0] > 0.f)) && total_sweeps >= 2;
     const bool segmented = depth_segments || tab_segments;
     std::vector<ChainScalars> sc(h->n_chains);
@@ -320,6 +333,13 @@ int bisbm_anneal(bisbm_handle h, int schedule, const float kwargs[2], uint64_t d
                                                       : (double)acc_sum[c] / (double)duration_steps;          // :100
         }
         HIPCHK(h, hipMemcpy(h->d_scalars, sc.data(), sizeof(ChainScalars) * h->n_chains, hipMemcpyHostToDevice));
+    }
+    if (sum_from_entropy) {
+        if (int rc = launch_block_entropy(h, h->d_tmp_f64)) return rc;
+        HIPCHK(h, launch_sum_from_entropy(h->d_scalars, h->d_ent_prev, h->d_tmp_f64, h->n_chains, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_ent_prev, h->d_tmp_f64, sizeof(double) * h->n_chains, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->ent_prev_valid = true;
     }
     for (uint32_t c = 0; c < h->n_chains; ++c)
         if (acc_rate_out) acc_rate_out[c] = sc[c].last_rate;

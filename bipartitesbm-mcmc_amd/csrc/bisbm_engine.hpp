@@ -100,6 +100,11 @@ struct bisbm_engine {
     double* d_T = nullptr;
     size_t d_T_cap = 0;
     double* d_tmp_f64 = nullptr;  // n_chains doubles
+    // block-state part of the description length of every chain as the last production launch without early-stop bookkeeping
+    // left it (such launches do not keep the running sum of accepted dS: bisbm_anneal advances it by the change of this,
+    // sweep_fast_tracks_minimum); valid while nothing else has changed the block state since
+    double* d_ent_prev = nullptr;
+    bool ent_prev_valid = false;
     uint32_t* d_stage_u32 = nullptr;  // n uint32 staging
     uint32_t* d_counts = nullptr;     // internal marginal buffer n*kmax
     uint32_t counts_kmax = 0;         // columns d_counts was sized for
@@ -162,6 +167,8 @@ void free_all(bisbm_engine* h);
 void mt_seed_host(uint32_t* mt, uint64_t seed);  // std::mt19937(seed): seed mod 2^32
 inline void forget_pass_speeds(bisbm_engine* h) { h->passes.reset(); }
 int rebuild_state(bisbm_engine* h);
+// block-state part of entropy() of every chain into d_out (n_chains doubles on the device), on the handle's stream, no sync
+int launch_block_entropy(bisbm_engine* h, double* d_out);
 
 // container handles (bisbm_engine::groups): run `f` on every group, first error wins
 template <class F>

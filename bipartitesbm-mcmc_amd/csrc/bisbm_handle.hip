@@ -27,7 +27,8 @@ int fail(bisbm_engine* h, int code, const char* fmt, ...) {
 void free_chain_arrays(bisbm_engine* h) {
     void** ptrs[] = {(void**)&h->d_labels, (void**)&h->d_labels_tmp, (void**)&h->d_vlist, (void**)&h->d_m, (void**)&h->d_m_r,
                      (void**)&h->d_n_r, (void**)&h->d_eta, (void**)&h->d_scalars, (void**)&h->d_mt_engine, (void**)&h->d_mt_gen,
-                     (void**)&h->d_tmp_f64, (void**)&h->d_counts, (void**)&h->d_gids};
+                     (void**)&h->d_tmp_f64, (void**)&h->d_counts, (void**)&h->d_gids, (void**)&h->d_ent_prev};
+    h->ent_prev_valid = false;
     for (void** p : ptrs)
         if (*p) {
             (void)hipFree(*p);
@@ -80,6 +81,7 @@ int rebuild_state(bisbm_engine* h) {
     HIPCHK(h, launch_state_build(bp, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->state_ready = true;
+    h->ent_prev_valid = false;
     // (a partition put in place from outside -- init, shuffle, merges, splits: the pass depths are measured afresh, see bisbm_anneal)
     forget_pass_speeds(h);
     return BISBM_OK;
@@ -97,6 +99,26 @@ size_t generic_lds_base_bytes(uint32_t ka, uint32_t kb, bool wide, int rng_mode)
     size_t lds = sizeof(int32_t) * ((wide ? 0 : (size_t)ka * S) + 2 * K + std::max<uint32_t>(std::max(ka, kb), 64)) + sizeof(uint32_t) * 64 * 64;
     if (rng_mode == BISBM_RNG_MT19937_COMPAT) lds += sizeof(uint32_t) * 624 * 4;
     return lds;
+}
+
+int launch_block_entropy(bisbm_engine* h, double* d_out) {
+    EntropyParams ep{};
+    ep.ka = h->ka;
+    ep.kb = h->kb;
+    ep.maxdeg = h->maxdeg;
+    ep.n_chains = h->n_chains;
+    ep.m = h->d_m;
+    ep.m_r = h->d_m_r;
+    ep.n_r = h->d_n_r;
+    ep.eta = h->d_eta;
+    ep.lgamma_tab = h->d_lgamma;
+    ep.lgamma_size = h->tab->lg.size();
+    ep.q_tab = h->d_q;
+    ep.q_stride = h->q_stride;
+    ep.log_tab = h->d_logtab;
+    ep.out = d_out;
+    HIPCHK(h, launch_entropy(ep, h->stream));
+    return BISBM_OK;
 }
 
 }  // namespace bisbm
@@ -478,22 +500,7 @@ int bisbm_entropy(bisbm_handle h, double* out) {
     if (!h->groups.empty()) return gather_groups<double>(h, out, [](bisbm_engine* g, double* o) { return bisbm_entropy(g, o); });
     if (!h->state_ready) return fail(h, BISBM_ERR_STATE, "block state not built yet");
     HIPCHK(h, hipSetDevice(h->device));
-    EntropyParams ep{};
-    ep.ka = h->ka;
-    ep.kb = h->kb;
-    ep.maxdeg = h->maxdeg;
-    ep.n_chains = h->n_chains;
-    ep.m = h->d_m;
-    ep.m_r = h->d_m_r;
-    ep.n_r = h->d_n_r;
-    ep.eta = h->d_eta;
-    ep.lgamma_tab = h->d_lgamma;
-    ep.lgamma_size = h->tab->lg.size();
-    ep.q_tab = h->d_q;
-    ep.q_stride = h->q_stride;
-    ep.log_tab = h->d_logtab;
-    ep.out = h->d_tmp_f64;
-    HIPCHK(h, launch_entropy(ep, h->stream));
+    if (int rc = launch_block_entropy(h, h->d_tmp_f64)) return rc;
     std::vector<double> part(h->n_chains);
     HIPCHK(h, hipMemcpyAsync(part.data(), h->d_tmp_f64, sizeof(double) * h->n_chains, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -1345,6 +1345,16 @@ hipError_t launch_shuffle(const ShuffleParams& p, int rng_mode, hipStream_t stre
     return hipGetLastError();
 }
 
+__global__ void sum_from_entropy_kernel(ChainScalars* scalars, const double* before, const double* after, uint32_t n_chains) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_chains) scalars[c].cum_dS += after[c] - before[c];
+}
+
+hipError_t launch_sum_from_entropy(ChainScalars* scalars, const double* before, const double* after, uint32_t n_chains, hipStream_t stream) {
+    hipLaunchKernelGGL(sum_from_entropy_kernel, dim3((n_chains + 255) / 256), dim3(256), 0, stream, scalars, before, after, n_chains);
+    return hipGetLastError();
+}
+
 hipError_t launch_entropy(const EntropyParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(entropy_kernel, dim3(p.n_chains), dim3(kWave), 0, stream, p);
     return hipGetLastError();

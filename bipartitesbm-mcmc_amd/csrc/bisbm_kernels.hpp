@@ -93,6 +93,10 @@ struct SweepParams {
     // wide mode (KA + KB > 256; generic kernel only): `labels` holds two-byte labels (label_stride counts labels, not
     // bytes), and the a x b quadrant of m is read and updated in HBM
     uint32_t wide;
+    // production kernel: keep the running sum of accepted dS (and the early-stop bookkeeping's code path) also in a launch
+    // that cannot stop early -- BISBM_KEEP_SUM=1: the tests that check the sum of the kernel's own dS values against the change
+    // of the description length, tools/soak.py
+    uint32_t keep_sum;
 };
 constexpr uint32_t kSimdClaims = 1u << 14;  // index: XCC_ID[3:0] | HW_ID se, sh, cu [15:8] | simd [5:4]
 
@@ -222,6 +226,17 @@ __device__ __forceinline__ double temperature_tabled(const SweepParams& p, uint6
         }
     }
 }
+
+// Production kernel: does a launch keep anneal()'s early-stop bookkeeping (metropolis_hasting.cc:85-98)?  It can only ever fire
+// below T = 1 and when steps_await can be reached within the call.  A launch that does not keep it does not keep the running sum
+// of accepted dS either (nobody looks at it during the launch): bisbm_anneal then advances the chain's sum by the change of the
+// block-state part of the description length over the call (entropy_kernel before and after; the two agree to ~1e-13 relative,
+// tests/test_gpu_scale.py), which takes the sum out of every pass.
+__host__ __device__ inline bool sweep_fast_tracks_minimum(int schedule, float kw0, uint64_t steps_await, uint64_t call_duration) {
+    return (schedule != SCHED_CONSTANT || (double)kw0 < 1.) && steps_await <= call_duration;
+}
+// scalars[c].cum_dS += after[c] - before[c]
+hipError_t launch_sum_from_entropy(ChainScalars* scalars, const double* before, const double* after, uint32_t n_chains, hipStream_t stream);
 
 hipError_t launch_sweep(const SweepParams& p, int rng_mode, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_sweep_fast(const SweepParams& p, size_t lds_bytes, hipStream_t stream);

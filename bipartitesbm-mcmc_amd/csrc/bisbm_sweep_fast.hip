@@ -244,7 +244,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     const bool quad32_mode = (uint32_t)__builtin_amdgcn_readfirstlane((Q32 && (!CT || T_const > 0.) && p.pair_steps > 1u) ? 1 : 0) != 0u;
     const bool oct_mode = (uint32_t)__builtin_amdgcn_readfirstlane((K8 && (!CT || T_const > 0.) && p.pair_steps > 2u) ? 1 : 0) != 0u;
     const uint32_t track_min =
-        (uint32_t)__builtin_amdgcn_readfirstlane(((!CT || T_const < 1.) && p.steps_await <= p.call_duration) ? 1 : 0);
+        (uint32_t)__builtin_amdgcn_readfirstlane((sweep_fast_tracks_minimum(p.schedule, p.kw0, p.steps_await, p.call_duration) || p.keep_sum != 0u) ? 1 : 0);
     // constants of the hot step (log_q closed form, accept filter)
     BISBM_PIN(c_l2e, 0x1.71547652b82fep+0);        // log2(e)
     double c_tol = 1e-5;                           // accept filter margin
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         eta_l[eta_at(r_loc, deg)] = (uint32_t)(eta_r - 1);
                         eta_l[eta_at(s_loc, deg)] = (uint32_t)(eta_s + 1);
                         new_lab[q] = (uint8_t)s;
-                        cum_l0 += dS;  // :500
+                        if constexpr (TM) cum_l0 += dS;  // :500 (without the bookkeeping: kSumFromEntropy)
                         acc_l0 += 1;
                     }
                     const int dl = (int)min(lb ^ r_loc, 1u) - (int)min(lb ^ s_loc, 1u);  // +1 on lane s_loc, -1 on r_loc
@@ -888,13 +888,17 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const int32_t kmask = (0 - k) >> 31;
                     const int32_t m_rt = m_rt_raw & kmask;
                     const uint32_t kk = (uint32_t)k;
-                    const double L1 = tab_at(tab.lg, (uint32_t)(m_rt + 1));
-                    const double L3 = tab_at(tab.lg, (uint32_t)(m_rt + 1) - kk);
-                    __asm__ volatile("" ::: "memory");
                     FSTAMP_STEP(1);
                     // inverse CDF per half (:627-628): the scan does not cross lane 31 -> 32
                     const int scan = wave_inclusive_scan32(w_piv);
                     const unsigned long long hit = __builtin_amdgcn_ballot_w64((uint32_t)scan > prop);
+                    // the two lgamma gathers that only need row r go out behind the vote (round 4: they are used on the tail and have
+                    // slack; in front of the scan their address arithmetic delayed the chain scan -> s -> the s-dependent gathers;
+                    // +0.5 %, profiles/r04_ab_pass_scheduling.txt)
+                    __asm__ volatile("" ::: "memory");
+                    const double L1 = tab_at(tab.lg, (uint32_t)(m_rt + 1));
+                    const double L3 = tab_at(tab.lg, (uint32_t)(m_rt + 1) - kk);
+                    __asm__ volatile("" ::: "memory");
                     uint32_t fhA, fhB;
                     __asm__("s_ff1_i32_b32 %0, %1" : "=s"(fhA) : "s"((uint32_t)hit));
                     __asm__("s_ff1_i32_b32 %0, %1" : "=s"(fhB) : "s"((uint32_t)(hit >> 32)));
@@ -1005,8 +1009,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     if ((TM ? (okA | okB) : (chA | chB)) != 0u) {  // (with the early-stop bookkeeping on: every accepted step is looked at)
                         // ---- apply_mcmc_moves, blockmodel.cc:461-503, for the step(s) that move: their rows differ ----
                         const uint32_t mA = 0u - chA, mB = 0u - chB;  // all ones / zero
-                        const int dS_A_lo = __builtin_amdgcn_readlane(__double2loint(dS), 31), dS_A_hi = __builtin_amdgcn_readlane(__double2hiint(dS), 31);
-                        const int dS_B_lo = __builtin_amdgcn_readlane(__double2loint(dS), 63), dS_B_hi = __builtin_amdgcn_readlane(__double2hiint(dS), 63);
                         const unsigned long long movers = ((unsigned long long)mB << 32) | mA;
                         wfence();
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & lanes_koth)) {  // k == 0: rewrites the same values
@@ -1018,13 +1020,16 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000000100000001ull)) new_lab[qs] = (uint8_t)(own_base + s_loc);
                         mr_own += (dmA & (int)mA) + (dmB & (int)mB);
                         nr_own += (dlA & (int)mA) + (dlB & (int)mB);
-                        // :500, in step order; a step that does not move adds +0.0 (x + 0.0 is x: the running sum is never -0.0)
-                        cum_l0 += __hiloint2double(dS_A_hi & (int)mA, dS_A_lo & (int)mA);
-                        if constexpr (TM)
+                        if constexpr (TM) {  // :500, in step order; without the early-stop bookkeeping nobody looks at the running sum
+                                             // during the launch: the host takes it from the description length (kSumFromEntropy)
+                            const int dS_A_lo = __builtin_amdgcn_readlane(__double2loint(dS), 31), dS_A_hi = __builtin_amdgcn_readlane(__double2hiint(dS), 31);
+                            const int dS_B_lo = __builtin_amdgcn_readlane(__double2loint(dS), 63), dS_B_hi = __builtin_amdgcn_readlane(__double2hiint(dS), 63);
+                            // (a step that does not move adds +0.0: x + 0.0 is x, the running sum is never -0.0)
+                            cum_l0 += __hiloint2double(dS_A_hi & (int)mA, dS_A_lo & (int)mA);
                             if (okA) new_minimum(q);  // (:86-90, after step q's move and before step q + 1's)
-                        cum_l0 += __hiloint2double(dS_B_hi & (int)mB, dS_B_lo & (int)mB);
-                        if constexpr (TM)
+                            cum_l0 += __hiloint2double(dS_B_hi & (int)mB, dS_B_lo & (int)mB);
                             if (okB) new_minimum(qB);
+                        }
                         wfence();
                     }
                     FSTAMP_STEP(8);
@@ -1161,8 +1166,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     acc_chunk += okA + okB;
                     if ((TM ? (okA | okB) : (chA | chB)) != 0u) {
                         const uint32_t mA = 0u - chA, mB = 0u - chB;
-                        const int dS_A_lo = __builtin_amdgcn_readlane(__double2loint(dS), 31), dS_A_hi = __builtin_amdgcn_readlane(__double2hiint(dS), 31);
-                        const int dS_B_lo = __builtin_amdgcn_readlane(__double2loint(dS), 63), dS_B_hi = __builtin_amdgcn_readlane(__double2hiint(dS), 63);
                         const unsigned long long movers = ((unsigned long long)mB << 32) | mA;
                         wfence();
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & lanes_koth64_lo)) {  // k == 0: rewrites the same values
@@ -1178,12 +1181,14 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         if (__builtin_amdgcn_inverse_ballot_w64(movers & 0x0000000100000001ull)) new_lab[qs] = (uint8_t)(own_base + s_loc);
                         mr_own += (dmA & (int)mA) + (dmB & (int)mB);
                         nr_own += (dlA & (int)mA) + (dlB & (int)mB);
-                        cum_l0 += __hiloint2double(dS_A_hi & (int)mA, dS_A_lo & (int)mA);
-                        if constexpr (TM)
+                        if constexpr (TM) {  // (see step_pair)
+                            const int dS_A_lo = __builtin_amdgcn_readlane(__double2loint(dS), 31), dS_A_hi = __builtin_amdgcn_readlane(__double2hiint(dS), 31);
+                            const int dS_B_lo = __builtin_amdgcn_readlane(__double2loint(dS), 63), dS_B_hi = __builtin_amdgcn_readlane(__double2hiint(dS), 63);
+                            cum_l0 += __hiloint2double(dS_A_hi & (int)mA, dS_A_lo & (int)mA);
                             if (okA) new_minimum(q);
-                        cum_l0 += __hiloint2double(dS_B_hi & (int)mB, dS_B_lo & (int)mB);
-                        if constexpr (TM)
+                            cum_l0 += __hiloint2double(dS_B_hi & (int)mB, dS_B_lo & (int)mB);
                             if (okB) new_minimum(qB);
+                        }
                         wfence();
                     }
                     return 1u + stands;
@@ -1338,7 +1343,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                                 const int dl = (int)min(lb ^ rg, 1u) - (int)min(lb ^ sg, 1u);  // +1 on lane s, -1 on lane r
                                 mr_own += __mul24((int)dg, dl);
                                 nr_own += dl;
-                                cum_l0 += readlane(dS, 16u * g + 15u);
+                                if constexpr (TM) cum_l0 += readlane(dS, 16u * g + 15u);
                                 if constexpr (TM) new_minimum(q + g);
                             } else if (TM && (((commit & selfok4) >> g) & 1u)) {
                                 new_minimum(q + g);  // an accepted r == s step (see new_minimum)
@@ -1527,7 +1532,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                                 const int dl = (int)min(lb ^ rg, 1u) - (int)min(lb ^ sg, 1u);  // +1 on lane s, -1 on lane r
                                 mr_own += __mul24((int)dg, dl);
                                 nr_own += dl;
-                                cum_l0 += readlane(dS, 16u * g + 15u);
+                                if constexpr (TM) cum_l0 += readlane(dS, 16u * g + 15u);
                                 if constexpr (TM) new_minimum(q + g);
                             } else if (TM && (((commit & selfok4) >> g) & 1u)) {
                                 new_minimum(q + g);  // an accepted r == s step (see new_minimum)
@@ -1681,7 +1686,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                                 const int dl = (int)min(lb ^ rg, 1u) - (int)min(lb ^ sg, 1u);
                                 mr_own += __mul24((int)dg, dl);
                                 nr_own += dl;
-                                cum_l0 += readlane(dS, 8u * g + 7u);
+                                if constexpr (TM) cum_l0 += readlane(dS, 8u * g + 7u);
                                 if constexpr (TM) new_minimum(q + g);
                             } else if (TM && (((commit & selfok8) >> g) & 1u)) {
                                 new_minimum(q + g);
@@ -1827,7 +1832,9 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
         for (int i = 0; i < 12; ++i) atomicAdd(&g_fast_stamps[i], st_acc[i]);
 #endif
     if (lane == 0) {
-        sc->cum_dS = cum_l0;
+        // (a launch without the early-stop bookkeeping has not kept the running sum: bisbm_anneal sets it from the change of the
+        // description length, sweep_fast_sum_from_entropy)
+        if (track_min != 0u) sc->cum_dS = cum_l0;
         sc->sweeps_total = sweeps_total;
         sc->last_rate = rate;
         sc->last_accepted = acc_l0;

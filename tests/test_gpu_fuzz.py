@@ -27,7 +27,9 @@ def _check(g, os_, what):
         assert (g.get_m(c) == o.m()).all() and (g.get_m_r(c) == o.m_r()).all(), (what, c)
         assert (g.get_n_r(c) == o.n_r()).all() and (g.get_eta_rk_(c) == o.eta()).all(), (what, c)
         assert abs(ent[c] - o.entropy()) <= 1e-9 * max(1.0, abs(o.entropy())), (what, c)
-        assert abs(cum[c] - o.get_entropy()) <= 1e-9 * max(1.0, abs(o.get_entropy())), (what, c)
+        # (the running sum advances per call by a difference of description lengths where no early stop is in reach: its error is
+        # a few ulps of S per call, not of the sum -- DESIGN.md section 6)
+        assert abs(cum[c] - o.get_entropy()) <= 1e-9 * max(1.0, abs(o.get_entropy())) + 1e-11 * abs(o.entropy()), (what, c)
 
 
 # BISBM_FUZZ_SEEDS=N widens the hunt (seeds >= 174 are further sequences of the small-graph kind)

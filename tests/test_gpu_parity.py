@@ -24,6 +24,15 @@ def gpu_model(rowptr, col, na, nb, ka, kb, eps, labels, **kw):
     return B.BlockModel(labels, SYN.types_vector(na, nb), ka + kb, ka, kb, eps, (rowptr, col), **kw)
 
 
+def sum_dS_close(got, o, rel=1e-9):
+    """The running sum of accepted dS against the oracle's: 1e-9 relative (north_star), plus what a DIFFERENCE of description
+    lengths can resolve -- a production launch without the early-stop bookkeeping advances the sum by the change of the
+    description length S over the call, so near the mode, where the sum hovers around zero, its error is
+    a few ulps of S (1e-12 |S| allowed), not of the sum."""
+    want = o.get_entropy()
+    return abs(got - want) <= rel * abs(want) + 1e-12 * abs(o.entropy())
+
+
 def assert_state_equal(g, o, chain=0):
     assert (g.get_memberships(chain) == o.memberships()).all()
     assert (g.get_m(chain) == o.m()).all()
@@ -132,7 +141,7 @@ def test_matches_oracle(case, mode):
         assert_state_equal(g, o)
         acc, sw = g.last_counts()
         assert acc[0] == o.last_accepted and sw[0] == o.last_sweeps
-        assert g.get_entropy()[0] == pytest.approx(o.get_entropy(), rel=1e-9, abs=1e-9)
+        assert sum_dS_close(g.get_entropy()[0], o) or abs(g.get_entropy()[0] - o.get_entropy()) <= 1e-9
     assert g.entropy()[0] == pytest.approx(o.entropy(), rel=1e-9)
 
 
@@ -163,7 +172,7 @@ def test_eta_window_in_lds(name, window, monkeypatch):
         for (s_, kw, dur, aw), rates in zip(runs, got):
             assert o.anneal(s_, kw, dur, aw) == rates[c], (s_, c)
         assert_state_equal(g, o, c)
-        assert g.get_entropy()[c] == pytest.approx(o.get_entropy(), rel=1e-9)
+        assert sum_dS_close(g.get_entropy()[c], o)
 
 
 def test_hot_step_many_chains_philox():
@@ -186,7 +195,7 @@ def test_hot_step_many_chains_philox():
         assert o.anneal("constant", [1.0], 2 * n, BIG) == rates[c]
         assert o.anneal("exponential", [2.0, 0.99995], 2 * n, BIG) == rates2[c]
         assert_state_equal(g, o, c)
-        assert cum[c] == pytest.approx(o.get_entropy(), rel=1e-9)
+        assert sum_dS_close(cum[c], o)
 
 
 @pytest.mark.parametrize("ka,kb", [(32, 32), (64, 64), (33, 57)])
@@ -237,7 +246,7 @@ def test_two_steps_per_pass_equals_the_serial_chain(ka, kb, monkeypatch):
             assert (g.get_memberships(c) == h.get_memberships(c)).all()
         assert np.allclose(g.get_entropy(), h.get_entropy(), rtol=0, atol=0)  # same sum, same order of additions
         for c, o in oracles:
-            assert g.get_entropy()[c] == pytest.approx(o.get_entropy(), rel=1e-9)
+            assert sum_dS_close(g.get_entropy()[c], o)
         if start == "planted":  # cooling schedules, the early stop armed, the greedy tail (T = 0), on the same chains
             for sched, kw, dur, aw in [("exponential", [1.5, 0.99997], 4 * n, n // 2), ("abrupt_cool", [1.5 * n], 3 * n, BIG),
                                        ("linear", [1.2, 1.0 / (2 * n)], 2 * n, BIG)]:
@@ -304,7 +313,7 @@ def test_four_and_eight_steps_per_pass_equal_the_serial_chain(monkeypatch):
             for (s, kw, sweeps, aw), r in zip(runs, rates):
                 assert o.anneal(s, kw, sweeps * n, aw) == r[c], (s, c)
             assert_state_equal(g, o, c)
-            assert g.get_entropy()[c] == pytest.approx(o.get_entropy(), rel=1e-9)
+            assert sum_dS_close(g.get_entropy()[c], o)
 
 
 @pytest.mark.parametrize("ka,kb,eps", [(32, 32, 1.0), (17, 29, 0.5), (24, 7, 1.0)])
@@ -359,7 +368,7 @@ def test_four_steps_per_pass_with_two_blocks_per_lane(ka, kb, eps, monkeypatch):
             for (s, kw, dur, aw), r in zip(runs, rates):
                 assert o.anneal(s, kw, dur, aw) == r[c], (start, s, c)
             assert_state_equal(g, o, c)
-            assert g.get_entropy()[c] == pytest.approx(o.get_entropy(), rel=1e-9)
+            assert sum_dS_close(g.get_entropy()[c], o)
 
 
 def test_pass_depth_is_chosen_from_timed_launches_and_never_changes_results(monkeypatch, capfd):
@@ -590,7 +599,7 @@ def test_config2_256_chains_philox():
             assert ent[c] == pytest.approx(o.entropy(), rel=1e-9)
         else:
             assert (g.get_memberships(c) == o.memberships()).all()
-        assert cum[c] == pytest.approx(o.get_entropy(), rel=1e-9)
+        assert sum_dS_close(cum[c], o)
         labs.append(o.memberships())
     # chains differ from each other
     assert len({tuple(l) for l in labs}) == chains
@@ -835,7 +844,7 @@ def test_chains_may_end_with_different_block_counts(mode):
         ent, cum = g.entropy(), g.get_entropy()
         for c, o in enumerate(os_):
             assert abs(ent[c] - o.entropy()) <= 1e-9 * abs(o.entropy())
-            assert abs(cum[c] - o.get_entropy()) <= 1e-9 * max(1.0, abs(o.get_entropy()))
+            assert sum_dS_close(cum[c], o) or abs(cum[c] - o.get_entropy()) <= 1e-9
 
     g.agg_merge(5, None, 10)
     for o in os_:
@@ -922,6 +931,39 @@ def test_cli_split_matches_oracle_replay():
     assert "(Ka, Kb) = (3, 4) " in r.stderr
 
 
+def test_running_sum_from_the_description_length_equals_the_sum_of_the_steps(monkeypatch):
+    """A production launch that cannot stop early does not add up its accepted dS step by step: bisbm_anneal advances the chain's
+    sum by the change of the block-state part of the description length over the call.  BISBM_KEEP_SUM=1 keeps the step-by-step
+    sum (the code path of the early-stop bookkeeping).  Same chains both ways: equal labels and rates, sums equal to a few ulps
+    of the description length S -- and each within the tolerance of the oracle's step-by-step sum."""
+    mh = B.MetropolisHasting()
+    rowptr, col = _random_graph(31, 6000, 6000, 150_000, 24, 31)
+    lab = O.contiguous_labels(6000, 6000, 24, 31)
+    n = 12_000
+    out = {}
+    for keep in ("0", "1"):
+        monkeypatch.setenv("BISBM_KEEP_SUM", keep)
+        g = gpu_model(rowptr, col, 6000, 6000, 24, 31, 1.0, lab, n_chains=5, rng="philox", seed=321)
+        g.shuffle_bisbm()
+        rates = [mh.anneal(g, "constant", [1.0], 3 * n, BIG).copy(), mh.anneal(g, "exponential", [1.5, 0.9999], 2 * n, BIG).copy(),
+                 mh.anneal(g, "exponential", [0.9, 0.9999], 2 * n, n // 2).copy(),  # (early stop in reach: step-by-step either way)
+                 mh.anneal(g, "constant", [2.0], n + 17, BIG).copy()]
+        out[keep] = (rates, [g.get_memberships(c) for c in range(5)], g.get_entropy().copy(), g.entropy().copy())
+    monkeypatch.delenv("BISBM_KEEP_SUM")
+    a, b = out["0"], out["1"]
+    assert all((x == y).all() for x, y in zip(a[0], b[0])) and all((x == y).all() for x, y in zip(a[1], b[1]))
+    assert (a[3] == b[3]).all()
+    assert (np.abs(a[2] - b[2]) <= 1e-12 * np.abs(a[3])).all(), (a[2], b[2])
+    o = O.OracleModel(rowptr, col, 6000, 6000, 24, 31, 1.0, lab)
+    o.seed_philox(321, 2)
+    o.shuffle_bisbm()
+    for (s, kw, dur, aw), r in zip([("constant", [1.0], 3 * n, BIG), ("exponential", [1.5, 0.9999], 2 * n, BIG),
+                                    ("exponential", [0.9, 0.9999], 2 * n, n // 2), ("constant", [2.0], n + 17, BIG)], a[0]):
+        assert o.anneal(s, kw, dur, aw) == r[2]
+    assert sum_dS_close(a[2][2], o) and sum_dS_close(b[2][2], o)
+    assert abs(b[2][2] - o.get_entropy()) <= 1e-9 * abs(o.get_entropy())  # (step by step: the tolerance of the sum itself)
+
+
 def test_anneal_splits_compose_on_device():
     rowptr, col, na, nb = O.load_graph("n_1000")
     labels = O.contiguous_labels(na, nb, 4, 6)
@@ -935,7 +977,11 @@ def test_anneal_splits_compose_on_device():
         for _ in range(5):
             mh.anneal(b, "constant", [1.0], 1000, BIG)
         assert (a.get_memberships() == b.get_memberships()).all()
-        assert a.get_entropy()[0] == b.get_entropy()[0]
+        if mode == "compat":
+            assert a.get_entropy()[0] == b.get_entropy()[0]
+        else:  # (production kernel without the early-stop bookkeeping: the sum advances per CALL by the change of the description
+               # length, so one call and five calls agree to rounding, not to the bit)
+            assert a.get_entropy()[0] == pytest.approx(b.get_entropy()[0], rel=1e-12, abs=1e-9)
 
 
 def test_device_log_q_matches_oracle():

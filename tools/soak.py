@@ -8,6 +8,8 @@ After many sweeps of every chain, three things must still hold for EVERY chain, 
     has ~1e8 terms per chain).
 usage: soak.py WORKLOAD SWEEPS [SCHEDULE K0 K1]      WORKLOAD = bench | n_1000 | config5
 """
+import os
+os.environ.setdefault('BISBM_KEEP_SUM', '1')  # the sum of the kernel's own dS values is what is checked against the description length
 import importlib
 import os
 import sys
