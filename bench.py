@@ -576,14 +576,14 @@ def main():
             return j, j.get("build") == tag
 
         if default_cfg:
-            tj, cur = tagged("r03_traffic.json")
+            tj, cur = tagged("r04_traffic.json")
             if tj:
                 traffic = tj["bytes_per_update"] * per_launch_updates
                 traffic_src = "%s (FETCH_SIZE+WRITE_SIZE, %.0f B per update%s; measured on build %s%s)" % (
-                    tj.get("_file", "profiles/r03_traffic.json"), tj["bytes_per_update"],
+                    tj.get("_file", "profiles/r04_traffic.json"), tj["bytes_per_update"],
                     ", calibration: " + tj["calibration"] if "calibration" in tj else "", tj.get("build"),
                     "" if cur else " -- NOT this build (%s): re-take with tools/profile.sh" % tag)
-            ij, cur = tagged("r03_issue.json")
+            ij, cur = tagged("r04_issue.json")
             if ij:
                 # Instruction-issue ceilings.  All kinds: a lone stepping wave per SIMD issues one instruction of any kind per
                 # >= 4 cycles, so updates/s <= SIMDs x clock / (instructions per update x 4).  VALU only: what the vector
@@ -596,9 +596,9 @@ def main():
                          "cycles_per_instruction": ISSUE_CYCLES, "simds": N_SIMDS, "clock_ghz": clk,
                          "peak_updates_per_s": peak, "achieved_updates_per_s": ups, "frac": ups / peak,
                          "valu_only_peak_updates_per_s": peak_valu, "valu_only_frac": ups / peak_valu,
-                         "source": ij.get("_file", "profiles/r03_issue.json"), "measured_on_build": ij.get("build"),
+                         "source": ij.get("_file", "profiles/r04_issue.json"), "measured_on_build": ij.get("build"),
                          "current_build": cur}
-            steady, cur = tagged("r03_steady_state.json")
+            steady, cur = tagged("r04_steady_state.json")
             if steady:
                 steady = dict(steady, current_build=cur)
         if steady_live is not None:

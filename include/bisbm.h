@@ -134,7 +134,11 @@ int bisbm_get_memberships(bisbm_handle h, uint32_t chain, uint32_t *labels_out);
 int bisbm_get_block_state(bisbm_handle h, uint32_t chain, int32_t *m, int32_t *m_r, int32_t *n_r,
                           uint32_t *eta);
 
-/* blockmodel_t::get_entropy (blockmodel.cc:91): running sum of accepted dS, per chain. */
+/* blockmodel_t::get_entropy (blockmodel.cc:91): running sum of accepted dS, per chain.  Launches that keep anneal()'s
+ * early-stop bookkeeping (below T = 1 with steps_await in reach), the generic kernel and mt19937-compat mode add it up step by
+ * step; a production launch that cannot stop early advances it per bisbm_anneal call by the change of the block-state part of
+ * the description length instead -- the same quantity to <= 1e-12 of the description length (BISBM_KEEP_SUM=1: step by step
+ * everywhere). */
 int bisbm_get_cum_dS(bisbm_handle h, double *out);
 
 /* blockmodel_t::entropy (blockmodel.cc:753-787): full description length, per chain.  The

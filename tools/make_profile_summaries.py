@@ -13,6 +13,28 @@ BUILD = os.environ.get("BISBM_BUILD_TAG") or build_tag()
 P = os.path.join(ROOT, "profiles")
 rnd, tag = sys.argv[1], sys.argv[2]
 pre = "%s_%s" % (rnd, tag)
+if len(sys.argv) > 3 and sys.argv[3] == "--config5":
+    # the K > 32 variant on the config-5 shape (N = 4e6, E = 5e7, Ka = Kb = 64, 1024 chains): instructions and bytes per update
+    rows = list(csv.DictReader(open(os.path.join(P, pre + "_pmc_counters.csv"))))
+    c = {r["counter"]: float(r["value_sum_over_launches"]) / int(r["launches"]) for r in rows}
+    ks = max((r for r in csv.DictReader(open(os.path.join(P, pre + "_kernel_stats.csv"))) if "sweep_fast" in r["Name"]), key=lambda r: int(r["Calls"]))
+    avg_s, upd = float(ks["AverageNs"]) / 1e9, 4.096e9
+    out = {"_file": "profiles/%s_config5_issue.json" % rnd, "build": BUILD, "kernel": ks["Name"],
+           "_what": "sweep_fast_kernel<*,*,false,...> (more than 32 blocks of a type: two steps per pass, two blocks per lane, a window of eta "
+                    "in LDS) at N_a = N_b = 2e6, E = 5e7, Ka = Kb = 64, 1024 chains: one sweep = 4.096e9 node updates per launch; rocprofv3 "
+                    "--pmc in separate passes, both waves of a chain",
+           "source": ["profiles/%s_pmc_counters.csv" % pre, "profiles/%s_kernel_stats.csv" % pre],
+           "instructions_per_update": sum(c[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_BRANCH", "SQ_INSTS_SMEM")) / upd,
+           "valu_per_update": c["SQ_INSTS_VALU"] / upd, "salu_per_update": c["SQ_INSTS_SALU"] / upd, "lds_per_update": c["SQ_INSTS_LDS"] / upd,
+           "vmem_per_update": c["SQ_INSTS_VMEM"] / upd, "branch_per_update": c["SQ_INSTS_BRANCH"] / upd,
+           "fetch_bytes_per_update_as_counted": c["FETCH_SIZE"] * 1024 / upd, "write_bytes_per_update": c["WRITE_SIZE"] * 1024 / upd,
+           "algorithmic_bytes_per_update": 8 + 5 * 25.0 + 2, "l2_hit_rate": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
+           "clock_ghz": c["GRBM_GUI_ACTIVE"] / 8 / avg_s / 1e9, "kernel_avg_s_under_rocprof": avg_s, "updates_per_s": upd / avg_s,
+           "wait_any_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], "active_inst_frac": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+           "lds_bank_conflict_frac": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]}
+    json.dump(out, open(os.path.join(P, rnd + "_config5_issue.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+    sys.exit(0)
 rows = list(csv.DictReader(open(os.path.join(P, pre + "_pmc_counters.csv"))))
 # (the counter passes pin the pass depth of the bench line's timed launches; should another variant of the kernel show up
 # anyway -- the depth is chosen per launch -- the one with the most launches is the one summarised)
