@@ -1,10 +1,10 @@
-"""The single-precision accept filter of the two-steps pass against the exact evaluation, at scale (diagnostic; round 4).
+"""The two forms of the two-steps pass against each other, at scale (diagnostic; round 4).
 
-A production launch that cannot stop early decides every accept on single-precision sums unless the decision is inside an error
-margin (then the exact double-precision evaluation decides).  BISBM_KEEP_SUM=1 runs the other form of the pass: every decision
-on the double-precision sums (the early-stop bookkeeping's code path).  If the margin were too narrow anywhere, some decision
-would differ and the two runs would part ways from that step on.  Here: the bench graph (or a denser / hub-heavy one), many chains,
-SWEEPS sweeps in both forms, constant T and a cooling call; every chain's labels, rates and accepted counts must be equal.
+A production launch that cannot stop early runs the pass WITHOUT the early-stop bookkeeping and the running sum; BISBM_KEEP_SUM=1
+runs the form WITH them in every launch.  Both must make every decision alike: same bench graph (or a denser / hub-heavy one),
+many chains, SWEEPS sweeps in both forms at constant T, a cooling call and a cold sweep; every chain's labels, rates and accepted
+counts must be equal.  (Written for the dropped single-precision accept filter, profiles/r04_ab_pass_scheduling.txt F1, whose
+decisions it compared with the all-double form over 1.7e10 steps; kept as the cross-check of the two forms.)
 usage: filter_vs_exact.py [SWEEPS] [CHAINS] [WORKLOAD]     WORKLOAD = bench | dense | hubs
 """
 import hashlib
@@ -47,6 +47,6 @@ for keep in ("0", "1"):
 a, b = out["0"], out["1"]
 same = all((x == y).all() for x, y in zip(a[:3], b[:3])) and a[3] == b[3] and (a[4] == b[4]).all()
 diff = [c for c in range(chains) if a[3][c] != b[3][c]]
-print("%s: %d chains x (%d + 4 + 1) sweeps of %d nodes = %.2e steps per form: filter == exact: %s%s" % (
+print("%s: %d chains x (%d + 4 + 1) sweeps of %d nodes = %.2e steps per form: both forms equal: %s%s" % (
     workload, chains, sweeps, n, chains * (sweeps + 5) * n, same, "" if same else "  (chains that differ: %s)" % diff[:10]), flush=True)
 sys.exit(0 if same else 1)
