@@ -50,6 +50,8 @@ def build_tag():
         if name.endswith((".hip", ".hpp", ".cpp")):
             with open(os.path.join(base, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
+    with open(os.path.join(ROOT, "bipartitesbm-mcmc_amd", "build.py"), "rb") as f:  # (the compiler flags are part of a build)
+        h.update(b"build.py\0" + f.read())
     return h.hexdigest()[:12]
 
 

@@ -25,7 +25,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          # emits the branches as written and updates the block state in place.
          "-mllvm", "-structurizecfg-skip-uniform-regions=true",
          # single-lane LDS atomics (the early-stop bookkeeping below T = 1) stay single instructions
-         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
+         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
+         # loop heads on 64-byte boundaries (the instruction cache's line): the pass loop of the production kernel is entered by a
+         # taken branch ~2 million times per chain and sweep, and where its head falls in a line is worth 1 % (same-box A/B with 32 /
+         # 64 / 128: profiles/r04_ab_pass_scheduling.txt) -- and it takes the placement noise out of every later A/B
+         "-falign-loops=64"]
 
 
 def hipcc():
