@@ -1064,9 +1064,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const int32_t kmask0 = (0 - k0) >> 31, kmask1 = (0 - k1) >> 31;
                     const int32_t m_rt0 = m_rt_raw0 & kmask0, m_rt1 = m_rt_raw1 & kmask1;
                     const uint32_t kk0 = (uint32_t)k0, kk1 = (uint32_t)k1;
-                    const double L1_0 = tab_at(tab.lg, (uint32_t)(m_rt0 + 1)), L3_0 = tab_at(tab.lg, (uint32_t)(m_rt0 + 1) - kk0);
-                    const double L1_1 = tab_at(tab.lg, (uint32_t)(m_rt1 + 1)), L3_1 = tab_at(tab.lg, (uint32_t)(m_rt1 + 1) - kk1);
-                    __asm__ volatile("" ::: "memory");
                     // inverse CDF per half over 64 own blocks (:627-628): the scan of blocks 0..31, its total, the scan of blocks
                     // 32..63 on top.  (Lanes past k_own hold garbage; block k_own - 1 always qualifies, and with k_own <= 32 the first
                     // hit lies in the lower scan, whose prefix sums up to it are clean.)
@@ -1075,6 +1072,11 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const int scan1 = wave_inclusive_scan32(w1) + tot;
                     const unsigned long long hit0 = __builtin_amdgcn_ballot_w64((uint32_t)scan0 > prop);
                     const unsigned long long hit1 = __builtin_amdgcn_ballot_w64((uint32_t)scan1 > prop);
+                    // (the four row-r gathers go out behind the votes, as in step_pair: +0.45 % on the config-5 shape, tools/ab_config5.sh)
+                    __asm__ volatile("" ::: "memory");
+                    const double L1_0 = tab_at(tab.lg, (uint32_t)(m_rt0 + 1)), L3_0 = tab_at(tab.lg, (uint32_t)(m_rt0 + 1) - kk0);
+                    const double L1_1 = tab_at(tab.lg, (uint32_t)(m_rt1 + 1)), L3_1 = tab_at(tab.lg, (uint32_t)(m_rt1 + 1) - kk1);
+                    __asm__ volatile("" ::: "memory");
                     const unsigned long long hitsA = (hit0 & 0xffffffffull) | (hit1 << 32), hitsB = (hit0 >> 32) | (hit1 & 0xffffffff00000000ull);
                     uint32_t fhA, fhB;
                     __asm__("s_ff1_i32_b64 %0, %1" : "=s"(fhA) : "s"(hitsA));
