@@ -252,3 +252,22 @@ def test_no_kernel_spills_vector_registers(built):
     spilled = {k: v["VGPRs Spill"] for k, v in usage.items() if v.get("VGPRs Spill", 0) != 0}
     assert not spilled, spilled
     assert all(v["VGPRs"] <= 256 and v["Occupancy [waves/SIMD]"] >= 2 for v in sweep.values())
+
+
+def test_bench_host_helpers():
+    """bench.py's host-side helpers (no GPU): the limits cpu_baseline sizes its worker pool by, the build tag the profile
+    summaries are matched with, and the algorithmic bytes per update of SURVEY 8(d)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    total, affinity, quota, mem = bench._cpu_limits()
+    assert total >= 1 and 1 <= affinity <= total and (quota is None or quota > 0) and (mem is None or mem > 0)
+    assert bench._worker_rss_bytes(1_000_000, 10_000_000) == pytest.approx(1.35e9, rel=0.05)  # (measured: 1.35 GB)
+    assert bench.b_alg_per_update(1_000_000, 10_000_000) == 110.0 and bench.b_alg_per_update(4_000_000, 50_000_000) == 135.0
+    tag = bench.build_tag()
+    assert len(tag) == 12 and tag == bench.build_tag()
+    # the three summaries the line quotes carry a build tag, and bench.py marks them when it is not the running build
+    for name in ("r04_traffic.json", "r04_issue.json", "r04_steady_state.json"):
+        j = bench.profile_json(name)
+        assert j is not None and len(j.get("build", "")) == 12, name
