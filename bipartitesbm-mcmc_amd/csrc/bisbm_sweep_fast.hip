@@ -102,6 +102,12 @@ __device__ __forceinline__ uint32_t smin(uint32_t x, uint32_t y) {
     return r;
 }
 
+#ifndef BISBM_PREDICT_TARGET
+#define BISBM_PREDICT_TARGET 2
+#endif
+#ifndef BISBM_PREDICT_TARGET64
+#define BISBM_PREDICT_TARGET64 1
+#endif
 constexpr uint32_t kHistStride = 68;  // bytes per k_v row: 64 counters + pad (17 dwords: odd, conflict-free)
 constexpr uint32_t kHandWords = 9;    // v, row begin, degree, own label, pivot label, proposal word, packed hot-step inputs, accept uniform (2)
 constexpr uint32_t kRowCap = 255;     // longest row the feeder walks (a k_v counter is a byte); longer rows: per-step side path
@@ -133,6 +139,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     }
     const uint32_t ka = p.ka, kb = p.kb, K = ka + kb, na = p.na, nb = p.nb;
     const uint32_t D = p.maxdeg + 1, S = kb | 1u;
+    // the two-steps pass of the K <= 32 variant starts from a predicted inverse-CDF target (see prepare and step_pair)
+    constexpr bool kPredictTarget = !K16 && !Q32 && (K32 ? BISBM_PREDICT_TARGET != 0 : BISBM_PREDICT_TARGET64 != 0);
     const uint32_t row_cap = p.maxdeg < kRowCap ? p.maxdeg : kRowCap;  // neighbours walked per row by the feeder
     // LDS layout, dword offsets
     const uint32_t o_mq = 0, o_eta = ka * S;
@@ -469,8 +477,25 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 if (k_own == 1u || deg_l == 0u || deg_l > kRowCap || (CT && T_const == 0.)) prop_l |= 0x80000000u;
                 if (!EL && deg_l - eta_lo >= eta_w) prop_l |= 0x80000000u;  // eta[.][deg] is not in the LDS window
                 hand[5 * kWave + lane] = prop_l;
-                // degree (<= 255 in the hot step), own block and pivot block in one word (one cross-lane move per pass)
-                hand[6 * kWave + lane] = (deg_l & 255u) | ((rloc_l & 63u) << 8) | (tloc_l << 16);
+                // The inverse-CDF target of the step as the block state stands NOW, one chunk ahead of the step (kPredictTarget:
+                // the two-steps pass of the K <= 32 variant): the first own-type block whose running sum of column m[.][t] exceeds x
+                // (:627-628).  A PREDICTION -- the stepping wave is moving nodes while this reads the matrix, and up to 128 steps
+                // will have run before the step itself -- that lets the step issue everything that depends on its target together
+                // with its first reads; the step still does the scan on the state of its own moment and goes ahead only when the
+                // two agree (a boundary of the running sums moves by a few units per chunk against bins of ~m_r / K: they do in
+                // all but ~1e-3 of the steps).
+                uint32_t spred_l = 0u;
+                if constexpr (kPredictTarget) {
+                    const uint32_t x = prop_l & 0x7fffffffu;
+                    uint32_t cum = 0u;
+                    for (uint32_t i = 0; i < k_own; ++i) {
+                        cum += (uint32_t)mq[mq_at(i, tloc_l)];
+                        spred_l += cum <= x ? 1u : 0u;
+                    }
+                    spred_l = spred_l < k_own ? spred_l : k_own - 1u;
+                }
+                // degree (<= 255 in the hot step), own block, pivot block and predicted target in one word (one cross-lane move per pass)
+                hand[6 * kWave + lane] = (deg_l & 255u) | ((rloc_l & 63u) << 8) | (tloc_l << 16) | (spred_l << 24);
                 *(double*)&hand[7 * kWave + 2 * lane] = ud_acc;  // (words 7, 8: the 64 accept uniforms as doubles)
                 wfence();
             };
@@ -489,7 +514,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 // proposal word, the accept uniform and 1 / T are read from LDS at a per-half / per-row address by every pass.)
                 new_lab[lane] = 0xffu;
                 const uint32_t pack_l = hand[6 * kWave + lane];
-                const unsigned long long gen_mask = __builtin_amdgcn_ballot_w64((int32_t)hand[5 * kWave + lane] < 0);  // steps that need the general path
+                unsigned long long gen_mask = __builtin_amdgcn_ballot_w64((int32_t)hand[5 * kWave + lane] < 0);  // steps that need the general path
                 auto prop_of = [&](uint32_t step) -> uint32_t { return hand[5 * kWave + step]; };
                 auto u_acc_of = [&](uint32_t step) -> double { return *(const double*)&hand[7 * kWave + 2 * step]; };
                 // the temperatures of the 64 steps (:84), lane = step: one table read or one pow / log per lane per chunk
@@ -730,7 +755,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         return;
                     }
                     const uint32_t pack = readlane(pack_l, q);
-                    const uint32_t deg = pack & 255u, r_loc = (pack >> 8) & 63u, t_loc = pack >> 16;
+                    const uint32_t deg = pack & 255u, r_loc = (pack >> 8) & 63u, t_loc = (pack >> 16) & 63u;
                     // early LDS reads: k_v counter of lane's block, row r of m, column t of m over v's own type
                     const int k = (int)hist8_cur[q * kHistStride + lane];
                     const uint32_t a_rt = mq_at(r_loc, lane);
@@ -873,7 +898,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double u_acc = u_acc_of(qs);
                     const uint32_t packA = readlane(pack_l, q), packB = readlane(pack_l, qB);
                     const uint32_t r_locA = (packA >> 8) & 63u, r_locB = (packB >> 8) & 63u;
-                    const uint32_t degA = packA & 255u, degB = packB & 255u, t_locA = packA >> 16, t_locB = packB >> 16;
+                    const uint32_t degA = packA & 255u, degB = packB & 255u, t_locA = (packA >> 16) & 63u, t_locB = (packB >> 16) & 63u;
                     // the lane's own step: lower half step q, upper half step qB (from the two scalars: no LDS round trip
                     // in front of the first reads)
                     const uint32_t deg = (uint32_t)((int)degA + __mul24((int)half, (int)degB - (int)degA));
@@ -888,17 +913,62 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const int32_t kmask = (0 - k) >> 31;
                     const int32_t m_rt = m_rt_raw & kmask;
                     const uint32_t kk = (uint32_t)k;
+                    const int ideg = (int)deg;
+                    // Everything that depends on the target s, as a function of the target's block index per half.  kPredictTarget:
+                    // evaluated on the feeder's PREDICTION (bits 24.. of the packed word), i.e. the reads of row s, eta and m_r / n_r
+                    // go out with the first reads and all six table gathers right behind them, while the scan that finds the
+                    // target on the state of this moment runs in their shadow; the pass goes ahead only where the two agree (below).
+                    // Otherwise (and in every other kind of pass): evaluated on the scan's result, behind it.
+                    uint32_t s_loc, idx_l, a_st, e_idx, tail_idx;
+                    int32_t m_st_raw, m_st;
+                    int ee, qn, qk;
+                    double logn, tail_lg, L1, L2, L3, L4;
+                    auto target_lds = [&](uint32_t sA, uint32_t sB) {  // row s of m, eta, m_r / n_r of r and s: LDS and cross-lane reads
+                        s_loc = (uint32_t)((int)sA + __mul24((int)half, (int)sB - (int)sA));
+                        idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
+                        a_st = mq_at(s_loc, lb);
+                        m_st_raw = mq[a_st];
+                        e_idx = eta_at(idx_l, deg);
+                        ee = (int)eta_l[e_idx];
+                        const int mm = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), mr_own);
+                        const int nn = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), nr_own);
+                        m_st = m_st_raw & kmask;
+                        qn = mm + __mul24(ideg, dsgn_l);        // m0r, m0s, m0r - deg, m0s + deg
+                        tail_idx = (uint32_t)((qn ^ ((qn ^ ee) & eta_mask_l)) + toff_l);
+                        qk = nn + dq_l;
+                    };
+                    auto target_gathers = [&]() {  // the four table gathers that depend on the target
+                        logn = tab_at(tab.logtab, (uint32_t)qn);
+                        tail_lg = tab_at(tab.lg, tail_idx);
+                        L2 = tab_at(tab.lg, (uint32_t)(m_st + 1));
+                        L4 = tab_at(tab.lg, (uint32_t)(m_st + 1) + kk);
+                    };
+                    auto row_r_gathers = [&]() {  // the two that only need row r
+                        L1 = tab_at(tab.lg, (uint32_t)(m_rt + 1));
+                        L3 = tab_at(tab.lg, (uint32_t)(m_rt + 1) - kk);
+                    };
+                    const uint32_t s_prdA = packA >> 24, s_prdB = packB >> 24;
+                    uint32_t pair_ok = pairable;  // step q + 1 is there and has been evaluated on its own target
+                    if constexpr (kPredictTarget) {
+                        target_lds(s_prdA, s_prdB);
+#if BISBM_PREDICT_TARGET != 4
+                        target_gathers();
+                        row_r_gathers();
+                        __asm__ volatile("" ::: "memory");
+#endif
+                    }
                     FSTAMP_STEP(1);
                     // inverse CDF per half (:627-628): the scan does not cross lane 31 -> 32
                     const int scan = wave_inclusive_scan32(w_piv);
                     const unsigned long long hit = __builtin_amdgcn_ballot_w64((uint32_t)scan > prop);
-                    // the two lgamma gathers that only need row r go out behind the vote (round 4: they are used on the tail and have
-                    // slack; in front of the scan their address arithmetic delayed the chain scan -> s -> the s-dependent gathers;
-                    // +0.5 %, profiles/r04_ab_pass_scheduling.txt)
-                    __asm__ volatile("" ::: "memory");
-                    const double L1 = tab_at(tab.lg, (uint32_t)(m_rt + 1));
-                    const double L3 = tab_at(tab.lg, (uint32_t)(m_rt + 1) - kk);
-                    __asm__ volatile("" ::: "memory");
+                    if constexpr (!kPredictTarget) {
+                        // the two lgamma gathers that only need row r go out behind the vote (round 4: they are used on the tail and have
+                        // slack; in front of the scan their address arithmetic delayed the chain scan -> s -> the s-dependent gathers;
+                        // +0.5 %, profiles/r04_ab_pass_scheduling.txt)
+                        __asm__ volatile("" ::: "memory");
+                        row_r_gathers();
+                        __asm__ volatile("" ::: "memory");
+                    }
                     uint32_t fhA, fhB;
                     __asm__("s_ff1_i32_b32 %0, %1" : "=s"(fhA) : "s"((uint32_t)hit));
                     __asm__("s_ff1_i32_b32 %0, %1" : "=s"(fhB) : "s"((uint32_t)(hit >> 32)));
@@ -916,23 +986,31 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         }
                         return 1u + pairable;
                     }
-                    const uint32_t s_loc = (uint32_t)((int)s_locA + __mul24((int)half, (int)s_locB - (int)s_locA));
-                    const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
-                    const uint32_t a_st = mq_at(s_loc, lb);
-                    const int32_t m_st_raw = mq[a_st];
-                    const uint32_t e_idx = eta_at(idx_l, deg);
-                    const int ee = (int)eta_l[e_idx];
-                    const int mm = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), mr_own);
-                    const int nn = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), nr_own);
-                    const int32_t m_st = m_st_raw & kmask;
-                    const int ideg = (int)deg;
-                    const int qn = mm + __mul24(ideg, dsgn_l);        // m0r, m0s, m0r - deg, m0s + deg
-                    const uint32_t tail_idx = (uint32_t)((qn ^ ((qn ^ ee) & eta_mask_l)) + toff_l);
-                    const int qk = nn + dq_l;
-                    const double logn = tab_at(tab.logtab, (uint32_t)qn);
-                    const double tail_lg = tab_at(tab.lg, tail_idx);
-                    const double L2 = tab_at(tab.lg, (uint32_t)(m_st + 1));
-                    const double L4 = tab_at(tab.lg, (uint32_t)(m_st + 1) + kk);
+                    if constexpr (kPredictTarget) {
+#if BISBM_PREDICT_TARGET == 2
+                        // a target that is not the predicted one: the reads that depend on it, again (nothing has been written)
+                        if (__builtin_expect(sflag((s_locA ^ s_prdA) | (s_locB ^ s_prdB)) != 0u, 0)) {
+                            target_lds(s_locA, s_locB);
+                            target_gathers();
+                        }
+#elif BISBM_PREDICT_TARGET == 4
+                        // a target that is not the predicted one: the reads that depend on it, again (nothing has been written); then
+                        // the six table gathers -- behind the test for "both r == s", so that a pass which ends there leaves nothing
+                        // in flight for the next one to wait for
+                        if (__builtin_expect(sflag((s_locA ^ s_prdA) | (s_locB ^ s_prdB)) != 0u, 0)) target_lds(s_locA, s_locB);
+                        target_gathers();
+                        row_r_gathers();
+#else
+                        // step q's target is not the predicted one: nothing has been written -- the caller sends step q down the
+                        // general path.  Step q + 1's is not: its evaluation does not stand, whatever step q does (it opens the next
+                        // pass, and goes the same way).
+                        if (__builtin_expect(s_locA != s_prdA, 0)) return 0u;
+                        pair_ok = pairable & (sflag(s_locB ^ s_prdB) ^ 1u);
+#endif
+                    } else {
+                        target_lds(s_locA, s_locB);
+                        target_gathers();
+                    }
                     FSTAMP_STEP(3);
                     // (the verdict logic's inputs are worked out here, while the table gathers are in flight -- after the gathers have
                     // been issued, not in front of them -- and pinned so that the compiler does not sink them behind the verdicts)
@@ -1002,7 +1080,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t yesA = (uint32_t)(b_acc >> 31) & 1u, yesB = (uint32_t)(b_acc >> 63) & 1u;
                     const uint32_t chA = flags & yesA;                                  // step q moves its node
                     const uint32_t okA = chA | ((flags >> 1) & 1u);                     // ... counts as accepted
-                    const uint32_t stands = pairable & ((chA & (flags >> 4)) ^ 1u);     // step q + 1's evaluation stands
+                    const uint32_t stands = pair_ok & ((chA & (flags >> 4)) ^ 1u);      // step q + 1's evaluation stands
                     const uint32_t chB = stands & (flags >> 2) & yesB;
                     const uint32_t okB = chB | (stands & (flags >> 3) & 1u);
                     acc_chunk += okA + okB;
@@ -1051,7 +1129,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const double u_acc = u_acc_of(qs);
                     const uint32_t packA = readlane(pack_l, q), packB = readlane(pack_l, qB);
                     const uint32_t r_locA = (packA >> 8) & 63u, r_locB = (packB >> 8) & 63u;
-                    const uint32_t degA = packA & 255u, degB = packB & 255u, t_locA = packA >> 16, t_locB = packB >> 16;
+                    const uint32_t degA = packA & 255u, degB = packB & 255u, t_locA = (packA >> 16) & 63u, t_locB = (packB >> 16) & 63u;
                     const uint32_t deg = (uint32_t)((int)degA + __mul24((int)half, (int)degB - (int)degA));
                     const uint32_t r_loc = (uint32_t)((int)r_locA + __mul24((int)half, (int)r_locB - (int)r_locA));
                     const uint32_t t_loc = (uint32_t)((int)t_locA + __mul24((int)half, (int)t_locB - (int)t_locA));
@@ -1064,6 +1142,44 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const int32_t kmask0 = (0 - k0) >> 31, kmask1 = (0 - k1) >> 31;
                     const int32_t m_rt0 = m_rt_raw0 & kmask0, m_rt1 = m_rt_raw1 & kmask1;
                     const uint32_t kk0 = (uint32_t)k0, kk1 = (uint32_t)k1;
+                    const int ideg = (int)deg;
+                    // what depends on the target s (see step_pair): on the feeder's prediction, in front of the scan (kPredictTarget), or on
+                    // the scan's result, behind it
+                    uint32_t s_loc, idx_l, a_st0, a_st1, e_idx, tail_idx;
+                    int32_t m_st_raw0, m_st_raw1, m_st0, m_st1;
+                    int ee, qn, qk;
+                    double tail_lg, logn, L1_0, L1_1, L2_0, L2_1, L3_0, L3_1, L4_0, L4_1;
+                    auto target_lds = [&](uint32_t sA, uint32_t sB) {
+                        s_loc = (uint32_t)((int)sA + __mul24((int)half, (int)sB - (int)sA));
+                        idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
+                        a_st0 = mq_at(s_loc, lh), a_st1 = mq_at(s_loc, lh + 32u);
+                        m_st_raw0 = mq[a_st0], m_st_raw1 = mq[a_st1];
+                        e_idx = eta_at(idx_l, deg);
+                        ee = (int)eta_l[e_idx];
+                        const int mm = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), mr_own);
+                        const int nn = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), nr_own);
+                        m_st0 = m_st_raw0 & kmask0, m_st1 = m_st_raw1 & kmask1;
+                        qn = mm + __mul24(ideg, dsgn_l);        // m0r, m0s, m0r - deg, m0s + deg
+                        tail_idx = (uint32_t)((qn ^ ((qn ^ ee) & eta_mask_l)) + toff_l);
+                        qk = nn + dq_l;
+                    };
+                    auto target_gathers = [&]() {
+                        tail_lg = tab_at(tab.lg, tail_idx);
+                        logn = tab_at(tab.logtab, (uint32_t)qn);
+                        L2_0 = tab_at(tab.lg, (uint32_t)(m_st0 + 1)), L4_0 = tab_at(tab.lg, (uint32_t)(m_st0 + 1) + kk0);
+                        L2_1 = tab_at(tab.lg, (uint32_t)(m_st1 + 1)), L4_1 = tab_at(tab.lg, (uint32_t)(m_st1 + 1) + kk1);
+                    };
+                    auto row_r_gathers = [&]() {
+                        L1_0 = tab_at(tab.lg, (uint32_t)(m_rt0 + 1)), L3_0 = tab_at(tab.lg, (uint32_t)(m_rt0 + 1) - kk0);
+                        L1_1 = tab_at(tab.lg, (uint32_t)(m_rt1 + 1)), L3_1 = tab_at(tab.lg, (uint32_t)(m_rt1 + 1) - kk1);
+                    };
+                    const uint32_t s_prdA = packA >> 24, s_prdB = packB >> 24;
+                    if constexpr (kPredictTarget) {
+                        target_lds(s_prdA, s_prdB);
+                        target_gathers();
+                        row_r_gathers();
+                        __asm__ volatile("" ::: "memory");
+                    }
                     // inverse CDF per half over 64 own blocks (:627-628): the scan of blocks 0..31, its total, the scan of blocks
                     // 32..63 on top.  (Lanes past k_own hold garbage; block k_own - 1 always qualifies, and with k_own <= 32 the first
                     // hit lies in the lower scan, whose prefix sums up to it are clean.)
@@ -1072,11 +1188,12 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const int scan1 = wave_inclusive_scan32(w1) + tot;
                     const unsigned long long hit0 = __builtin_amdgcn_ballot_w64((uint32_t)scan0 > prop);
                     const unsigned long long hit1 = __builtin_amdgcn_ballot_w64((uint32_t)scan1 > prop);
-                    // (the four row-r gathers go out behind the votes, as in step_pair: +0.45 % on the config-5 shape, tools/ab_config5.sh)
-                    __asm__ volatile("" ::: "memory");
-                    const double L1_0 = tab_at(tab.lg, (uint32_t)(m_rt0 + 1)), L3_0 = tab_at(tab.lg, (uint32_t)(m_rt0 + 1) - kk0);
-                    const double L1_1 = tab_at(tab.lg, (uint32_t)(m_rt1 + 1)), L3_1 = tab_at(tab.lg, (uint32_t)(m_rt1 + 1) - kk1);
-                    __asm__ volatile("" ::: "memory");
+                    if constexpr (!kPredictTarget) {
+                        // (the four row-r gathers go out behind the votes, as in step_pair: +0.45 % on the config-5 shape, tools/ab_config5.sh)
+                        __asm__ volatile("" ::: "memory");
+                        row_r_gathers();
+                        __asm__ volatile("" ::: "memory");
+                    }
                     const unsigned long long hitsA = (hit0 & 0xffffffffull) | (hit1 << 32), hitsB = (hit0 >> 32) | (hit1 & 0xffffffff00000000ull);
                     uint32_t fhA, fhB;
                     __asm__("s_ff1_i32_b64 %0, %1" : "=s"(fhA) : "s"(hitsA));
@@ -1093,23 +1210,16 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         }
                         return 1u + pairable;
                     }
-                    const uint32_t s_loc = (uint32_t)((int)s_locA + __mul24((int)half, (int)s_locB - (int)s_locA));
-                    const uint32_t idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
-                    const uint32_t a_st0 = mq_at(s_loc, lh), a_st1 = mq_at(s_loc, lh + 32u);
-                    const int32_t m_st_raw0 = mq[a_st0], m_st_raw1 = mq[a_st1];
-                    const uint32_t e_idx = eta_at(idx_l, deg);
-                    const int ee = (int)eta_l[e_idx];
-                    const int mm = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), mr_own);
-                    const int nn = __builtin_amdgcn_ds_bpermute((int)(idx_l << 2), nr_own);
-                    const int32_t m_st0 = m_st_raw0 & kmask0, m_st1 = m_st_raw1 & kmask1;
-                    const int ideg = (int)deg;
-                    const int qn = mm + __mul24(ideg, dsgn_l);        // m0r, m0s, m0r - deg, m0s + deg
-                    const uint32_t tail_idx = (uint32_t)((qn ^ ((qn ^ ee) & eta_mask_l)) + toff_l);
-                    const int qk = nn + dq_l;
-                    const double tail_lg = tab_at(tab.lg, tail_idx);
-                    const double logn = tab_at(tab.logtab, (uint32_t)qn);
-                    const double L2_0 = tab_at(tab.lg, (uint32_t)(m_st0 + 1)), L4_0 = tab_at(tab.lg, (uint32_t)(m_st0 + 1) + kk0);
-                    const double L2_1 = tab_at(tab.lg, (uint32_t)(m_st1 + 1)), L4_1 = tab_at(tab.lg, (uint32_t)(m_st1 + 1) + kk1);
+                    if constexpr (kPredictTarget) {
+                        // a target that is not the predicted one: the reads that depend on it, again (nothing has been written)
+                        if (__builtin_expect(sflag((s_locA ^ s_prdA) | (s_locB ^ s_prdB)) != 0u, 0)) {
+                            target_lds(s_locA, s_locB);
+                            target_gathers();
+                        }
+                    } else {
+                        target_lds(s_locA, s_locB);
+                        target_gathers();
+                    }
                     // (worked out while the gathers are in flight and pinned there, see step_pair: the verdict logic's inputs ...)
                     // would step q, if it moves its node, touch what step q + 1 read?  (step_pair's rule on 64-bit block sets)
                     const unsigned long long setA = (1ull << r_locA) | (1ull << s_locA), setB = (1ull << r_locB) | (1ull << s_locB);
@@ -1211,7 +1321,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t prop = prop_of(qs);
                     const uint32_t pack = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)pack_l);
                     const double u_acc = u_acc_of(qs);
-                    const uint32_t deg = pack & 255u, r_loc = (pack >> 8) & 63u, t_loc = pack >> 16;
+                    const uint32_t deg = pack & 255u, r_loc = (pack >> 8) & 63u, t_loc = (pack >> 16) & 63u;
                     const int k = (int)hist8_cur[qs * kHistStride + lb];
                     const uint32_t a_rt = mq_at(r_loc, lb);
                     const int32_t m_rt_raw = mq[a_rt];
@@ -1384,7 +1494,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t prop = prop_of(qs);
                     const uint32_t pack = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)pack_l);
                     const double u_acc = u_acc_of(qs);
-                    const uint32_t deg = pack & 255u, r_loc = (pack >> 8) & 63u, t_loc = pack >> 16;
+                    const uint32_t deg = pack & 255u, r_loc = (pack >> 8) & 63u, t_loc = (pack >> 16) & 63u;
                     const int k0 = (int)hist8_cur[qs * kHistStride + l16], k1 = (int)hist8_cur[qs * kHistStride + l16 + 16u];
                     const uint32_t a_rt0 = mq_at(r_loc, l16), a_rt1 = mq_at(r_loc, l16 + 16u);
                     const int32_t m_rt_raw0 = mq[a_rt0], m_rt_raw1 = mq[a_rt1];
@@ -1571,7 +1681,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t prop = prop_of(qs);
                     const uint32_t pack = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)pack_l);
                     const double u_acc = u_acc_of(qs);
-                    const uint32_t deg = pack & 255u, r_loc = (pack >> 8) & 63u, t_loc = pack >> 16;
+                    const uint32_t deg = pack & 255u, r_loc = (pack >> 8) & 63u, t_loc = (pack >> 16) & 63u;
                     const int k = (int)hist8_cur[qs * kHistStride + lb];
                     const uint32_t a_rt = mq_at(r_loc, lb);
                     const int32_t m_rt_raw = mq[a_rt];
@@ -1723,7 +1833,11 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                             step_general(q, T_of_step(q));
                             q += 1u;
                         } else if (K32) {
-                            q += step_pair(tm, q, ((two >> 1) ^ 1u) & sflag(cnt - 1u - q));
+                            const uint32_t done = step_pair(tm, q, ((two >> 1) ^ 1u) & sflag(cnt - 1u - q));
+                            if constexpr (kPredictTarget && BISBM_PREDICT_TARGET == 1) {  // (0: the predicted target of step q was not its target -- the general path takes it)
+                                if (__builtin_expect(done == 0u, 0)) gen_mask |= 1ull << q;
+                            }
+                            q += done;
                         } else {  // (one step per pass, BISBM_SINGLE_STEPS=1: a pass whose two halves evaluate the same step)
                             q += step_pair64(tm, q, ((two >> 1) ^ 1u) & sflag(cnt - 1u - q) & (pair64_mode ? 1u : 0u));
                         }

@@ -226,12 +226,15 @@ def test_deep_passes_at_full_size(k, monkeypatch):
 
 
 # ------------------------------------------------------------------ BASELINE configs[4]: per-GPU shape
-@pytest.mark.parametrize("chains,container", [(256, False), (1024, True)])
+@pytest.mark.parametrize("chains,container", [(256, 0), (1024, 1), (8192, 8)])
 def test_config5_shape_properties(chains, container, monkeypatch, capfd):
     """N_a = N_b = 2e6, E = 5e7, Ka = Kb = 64 (the K > 32 variant of the production kernel: two steps per pass with two
     blocks per lane, a window of eta in LDS) -- the per-GPU shape of BASELINE configs[4], at a quarter of its chains on a plain
-    handle and at its full per-GPU load of 1024 chains behind a multi-device handle over this one device (`devices=[0]`: what
-    each GPU of the 8-GPU configuration runs, pooling of the marginals through RCCL included): a sweep at constant T and a
+    handle, at its full per-GPU load of 1024 chains behind a multi-device handle over this one device (`devices=[0]`: what
+    each GPU of the 8-GPU configuration runs, pooling of the marginals through RCCL included), and at the configuration's own
+    chain count -- 8192 chains behind a handle of EIGHT device entries, 1024 chains each, all eight on this one GPU (the
+    sharding, the per-entry engines side by side and the pooled marginals over eight 1 GB histograms as the 8-GPU node would
+    run them, the exchange as peer copies because the entries are one device): a sweep at constant T and a
     sweep under a cooling schedule keep the incremental state equal to a recount, block sizes sum to N, and the sum of accepted
     dS equals the change of the full description length, in every chain."""
     na = nb = 2_000_000
@@ -242,7 +245,7 @@ def test_config5_shape_properties(chains, container, monkeypatch, capfd):
     del a, b
     labels = SYN.contiguous_labels(na, nb, ka, kb)
     monkeypatch.setenv("BISBM_POOL_LOG", "1")
-    g = gpu_model(rowptr, col, na, nb, ka, kb, 1.0, labels, n_chains=chains, rng="philox", seed=5, **({"devices": [0]} if container else {}))
+    g = gpu_model(rowptr, col, na, nb, ka, kb, 1.0, labels, n_chains=chains, rng="philox", seed=5, **({"devices": [0] * container} if container else {}))
     g.shuffle_bisbm()
     s0 = g.entropy()
     rates = B.MetropolisHasting().anneal(g, "constant", [1.0], na + nb, BIG)
@@ -276,7 +279,10 @@ def test_config5_shape_properties(chains, container, monkeypatch, capfd):
         capfd.readouterr()
         lab_map = g.marginals_map()
         log = capfd.readouterr().err
-        assert "[bisbm pool] RCCL path" in log and "peer-copy" not in log, log
+        if container == 1:
+            assert "[bisbm pool] RCCL path" in log and "peer-copy" not in log, log
+        else:
+            assert "[bisbm pool] peer-copy path" in log and "RCCL path" not in log, log
         counts = g.marginals_get()
         assert counts.shape == (na + nb, 64) and int(counts.sum()) == chains * (na + nb)
         want = counts.argmax(axis=1) + np.where(np.arange(na + nb) >= na, ka, 0)
