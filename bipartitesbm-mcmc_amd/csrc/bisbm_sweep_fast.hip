@@ -106,7 +106,7 @@ __device__ __forceinline__ uint32_t smin(uint32_t x, uint32_t y) {
 #define BISBM_PREDICT_TARGET 2
 #endif
 #ifndef BISBM_PREDICT_TARGET64
-#define BISBM_PREDICT_TARGET64 1
+#define BISBM_PREDICT_TARGET64 3
 #endif
 constexpr uint32_t kHistStride = 68;  // bytes per k_v row: 64 counters + pad (17 dwords: odd, conflict-free)
 constexpr uint32_t kHandWords = 9;    // v, row begin, degree, own label, pivot label, proposal word, packed hot-step inputs, accept uniform (2)
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     // constants of the hot step (log_q closed form, accept filter)
     BISBM_PIN(c_l2e, 0x1.71547652b82fep+0);        // log2(e)
     double c_tol = 1e-5;                           // accept filter margin
-    if (!(Q32 && !CT)) __asm__ volatile("" : "+v"(c_tol));  // (pinned, except in the variant where registers are scarcest)
+    if (!(Q32 && !CT) && !(!K32 && !EL && !CT)) __asm__ volatile("" : "+v"(c_tol));  // (pinned, except in the variants where registers are scarcest)
     LogQConsts lqc = log_q_consts();  // log_q closed form
     if (!(Q32 && !EL))  // (held in vector registers for the whole kernel, except where registers are scarcest: built at the use there)
         __asm__ volatile("" : "+v"(lqc.nc0l2e), "+v"(lqc.c1c0), "+v"(lqc.c1), "+v"(lqc.c2c0), "+v"(lqc.lfc));
@@ -1177,7 +1177,9 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     if constexpr (kPredictTarget) {
                         target_lds(s_prdA, s_prdB);
                         target_gathers();
+#if BISBM_PREDICT_TARGET64 != 2
                         row_r_gathers();
+#endif
                         __asm__ volatile("" ::: "memory");
                     }
                     // inverse CDF per half over 64 own blocks (:627-628): the scan of blocks 0..31, its total, the scan of blocks
@@ -1188,7 +1190,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const int scan1 = wave_inclusive_scan32(w1) + tot;
                     const unsigned long long hit0 = __builtin_amdgcn_ballot_w64((uint32_t)scan0 > prop);
                     const unsigned long long hit1 = __builtin_amdgcn_ballot_w64((uint32_t)scan1 > prop);
-                    if constexpr (!kPredictTarget) {
+                    if constexpr (!kPredictTarget || BISBM_PREDICT_TARGET64 == 2) {
                         // (the four row-r gathers go out behind the votes, as in step_pair: +0.45 % on the config-5 shape, tools/ab_config5.sh)
                         __asm__ volatile("" ::: "memory");
                         row_r_gathers();
@@ -1210,12 +1212,21 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         }
                         return 1u + pairable;
                     }
+                    uint32_t pair_ok = pairable;  // step q + 1 is there and has been evaluated on its own target
                     if constexpr (kPredictTarget) {
+#if BISBM_PREDICT_TARGET64 == 3
+                        // step q's target is not the predicted one: nothing has been written -- the caller sends step q down the general
+                        // path.  Step q + 1's is not: its evaluation does not stand, whatever step q does (it opens the next pass, and
+                        // goes the same way).  (step_pair issues the reads again in place instead; here that costs registers)
+                        if (__builtin_expect(s_locA != s_prdA, 0)) return 0u;
+                        pair_ok = pairable & (sflag(s_locB ^ s_prdB) ^ 1u);
+#else
                         // a target that is not the predicted one: the reads that depend on it, again (nothing has been written)
                         if (__builtin_expect(sflag((s_locA ^ s_prdA) | (s_locB ^ s_prdB)) != 0u, 0)) {
                             target_lds(s_locA, s_locB);
                             target_gathers();
                         }
+#endif
                     } else {
                         target_lds(s_locA, s_locB);
                         target_gathers();
@@ -1272,7 +1283,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t yesA = (uint32_t)(b_acc >> 31) & 1u, yesB = (uint32_t)(b_acc >> 63) & 1u;
                     const uint32_t chA = flags & yesA;
                     const uint32_t okA = chA | ((flags >> 1) & 1u);
-                    const uint32_t stands = pairable & ((chA & (flags >> 4)) ^ 1u);
+                    const uint32_t stands = pair_ok & ((chA & (flags >> 4)) ^ 1u);
                     const uint32_t chB = stands & (flags >> 2) & yesB;
                     const uint32_t okB = chB | (stands & (flags >> 3) & 1u);
                     acc_chunk += okA + okB;
@@ -1839,7 +1850,11 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                             }
                             q += done;
                         } else {  // (one step per pass, BISBM_SINGLE_STEPS=1: a pass whose two halves evaluate the same step)
-                            q += step_pair64(tm, q, ((two >> 1) ^ 1u) & sflag(cnt - 1u - q) & (pair64_mode ? 1u : 0u));
+                            const uint32_t done = step_pair64(tm, q, ((two >> 1) ^ 1u) & sflag(cnt - 1u - q) & (pair64_mode ? 1u : 0u));
+                            if constexpr (kPredictTarget && BISBM_PREDICT_TARGET64 == 3) {  // (0: see step_pair64)
+                                if (__builtin_expect(done == 0u, 0)) gen_mask |= 1ull << q;
+                            }
+                            q += done;
                         }
                     }
                     acc_l0 += (unsigned long long)acc_chunk;
