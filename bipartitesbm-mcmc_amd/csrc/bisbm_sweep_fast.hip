@@ -105,6 +105,15 @@ __device__ __forceinline__ uint32_t smin(uint32_t x, uint32_t y) {
 #ifndef BISBM_PREDICT_TARGET
 #define BISBM_PREDICT_TARGET 2
 #endif
+#ifndef BISBM_PACK_SELECT
+#define BISBM_PACK_SELECT 1
+#endif
+// x (a 0 / 1 word) in the upper half of the wave, 0 in the lower
+#if BISBM_PACK_SELECT
+#define BISBM_HALF_AND(x) ((uint32_t)half_mask_l & (x))
+#else
+#define BISBM_HALF_AND(x) (half & (0u - (x)))
+#endif
 #ifndef BISBM_PREDICT_TARGET64
 #define BISBM_PREDICT_TARGET64 3
 #endif
@@ -882,6 +891,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 // bit: the CPU checker steps one node at a time and the parity tests compare against it (measured on the
                 // bench workload: the second step stands in ~80 % of the passes, 1.8 steps per pass).
                 const uint32_t half = lane >> 5;
+                int half_mask_l = lane >= 32u ? -1 : 0;  // (all ones in the upper half: a per-lane select of two scalar words as bit operations)
+                __asm__ volatile("" : "+v"(half_mask_l));
                 uint32_t acc_chunk = 0;  // accepted steps of the chunk's pair passes (a scalar word; added to acc_l0 per chunk)
                 // q: first step of the pass; pairable: 1 = lanes 32..63 evaluate step q + 1, 0 = nothing to pair with
                 // (last step of the chunk, or a step that needs the general path next): both halves evaluate step q
@@ -890,7 +901,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 auto step_pair = [&](auto tm, uint32_t q, uint32_t pairable) -> uint32_t {
                     constexpr bool TM = decltype(tm)::value;
                     const uint32_t qB = q + pairable;
-                    const uint32_t qs = q + (half & (0u - pairable));  // (flags are 0 / 1 words and selections arithmetic: a bool
+                    const uint32_t qs = q + BISBM_HALF_AND(pairable);  // (flags are 0 / 1 words and selections arithmetic: a bool
                                                                          // select of uniform values goes through the vector unit and back)
                     const int sel = (int)(qs << 2);
                     FSTAMP_STEP(0);
@@ -901,9 +912,16 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t degA = packA & 255u, degB = packB & 255u, t_locA = (packA >> 16) & 63u, t_locB = (packB >> 16) & 63u;
                     // the lane's own step: lower half step q, upper half step qB (from the two scalars: no LDS round trip
                     // in front of the first reads)
+#if BISBM_PACK_SELECT
+                    // (one select of the whole packed word per lane, then the fields out of it: 6 instructions where four selects
+                    // of the scalar fields took 12)
+                    const uint32_t pack_v = packA ^ ((packA ^ packB) & (uint32_t)half_mask_l);
+                    const uint32_t deg = pack_v & 255u, r_loc = (pack_v >> 8) & 63u, t_loc = (pack_v >> 16) & 63u;
+#else
                     const uint32_t deg = (uint32_t)((int)degA + __mul24((int)half, (int)degB - (int)degA));
                     const uint32_t r_loc = (uint32_t)((int)r_locA + __mul24((int)half, (int)r_locB - (int)r_locA));
                     const uint32_t t_loc = (uint32_t)((int)t_locA + __mul24((int)half, (int)t_locB - (int)t_locA));
+#endif
                     const int k = (int)hist8_cur[qs * kHistStride + lb];
                     const uint32_t a_rt = mq_at(r_loc, lb);
                     const int32_t m_rt_raw = mq[a_rt];
@@ -923,8 +941,13 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     int32_t m_st_raw, m_st;
                     int ee, qn, qk;
                     double logn, tail_lg, L1, L2, L3, L4;
-                    auto target_lds = [&](uint32_t sA, uint32_t sB) {  // row s of m, eta, m_r / n_r of r and s: LDS and cross-lane reads
-                        s_loc = (uint32_t)((int)sA + __mul24((int)half, (int)sB - (int)sA));
+                    auto target_lds = [&](uint32_t sA, uint32_t sB, bool predicted) {  // row s of m, eta, m_r / n_r of r and s: LDS and cross-lane reads
+#if BISBM_PACK_SELECT
+                        if (predicted)
+                            s_loc = pack_v >> 24;
+                        else
+#endif
+                            s_loc = sA + ((sB - sA) & (uint32_t)half_mask_l);
                         idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
                         a_st = mq_at(s_loc, lb);
                         m_st_raw = mq[a_st];
@@ -950,7 +973,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t s_prdA = packA >> 24, s_prdB = packB >> 24;
                     uint32_t pair_ok = pairable;  // step q + 1 is there and has been evaluated on its own target
                     if constexpr (kPredictTarget) {
-                        target_lds(s_prdA, s_prdB);
+                        target_lds(s_prdA, s_prdB, true);
 #if BISBM_PREDICT_TARGET != 4
                         target_gathers();
                         row_r_gathers();
@@ -990,14 +1013,14 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
 #if BISBM_PREDICT_TARGET == 2
                         // a target that is not the predicted one: the reads that depend on it, again (nothing has been written)
                         if (__builtin_expect(sflag((s_locA ^ s_prdA) | (s_locB ^ s_prdB)) != 0u, 0)) {
-                            target_lds(s_locA, s_locB);
+                            target_lds(s_locA, s_locB, false);
                             target_gathers();
                         }
 #elif BISBM_PREDICT_TARGET == 4
                         // a target that is not the predicted one: the reads that depend on it, again (nothing has been written); then
                         // the six table gathers -- behind the test for "both r == s", so that a pass which ends there leaves nothing
                         // in flight for the next one to wait for
-                        if (__builtin_expect(sflag((s_locA ^ s_prdA) | (s_locB ^ s_prdB)) != 0u, 0)) target_lds(s_locA, s_locB);
+                        if (__builtin_expect(sflag((s_locA ^ s_prdA) | (s_locB ^ s_prdB)) != 0u, 0)) target_lds(s_locA, s_locB, false);
                         target_gathers();
                         row_r_gathers();
 #else
@@ -1008,7 +1031,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         pair_ok = pairable & (sflag(s_locB ^ s_prdB) ^ 1u);
 #endif
                     } else {
-                        target_lds(s_locA, s_locB);
+                        target_lds(s_locA, s_locB, false);
                         target_gathers();
                     }
                     FSTAMP_STEP(3);
@@ -1123,16 +1146,21 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                                 auto step_pair64 = [&](auto tm, uint32_t q, uint32_t pairable) -> uint32_t {
                     constexpr bool TM = decltype(tm)::value;
                     const uint32_t qB = q + pairable;
-                    const uint32_t qs = q + (half & (0u - pairable));
+                    const uint32_t qs = q + BISBM_HALF_AND(pairable);
                     const int sel = (int)(qs << 2);
                     const uint32_t prop = prop_of(qs);
                     const double u_acc = u_acc_of(qs);
                     const uint32_t packA = readlane(pack_l, q), packB = readlane(pack_l, qB);
                     const uint32_t r_locA = (packA >> 8) & 63u, r_locB = (packB >> 8) & 63u;
                     const uint32_t degA = packA & 255u, degB = packB & 255u, t_locA = (packA >> 16) & 63u, t_locB = (packB >> 16) & 63u;
+#if BISBM_PACK_SELECT
+                    const uint32_t pack_v = packA ^ ((packA ^ packB) & (uint32_t)half_mask_l);  // (see step_pair)
+                    const uint32_t deg = pack_v & 255u, r_loc = (pack_v >> 8) & 63u, t_loc = (pack_v >> 16) & 63u;
+#else
                     const uint32_t deg = (uint32_t)((int)degA + __mul24((int)half, (int)degB - (int)degA));
                     const uint32_t r_loc = (uint32_t)((int)r_locA + __mul24((int)half, (int)r_locB - (int)r_locA));
                     const uint32_t t_loc = (uint32_t)((int)t_locA + __mul24((int)half, (int)t_locB - (int)t_locA));
+#endif
                     const int k0 = (int)hist8_cur[qs * kHistStride + lh], k1 = (int)hist8_cur[qs * kHistStride + lh + 32u];
                     const uint32_t a_rt0 = mq_at(r_loc, lh), a_rt1 = mq_at(r_loc, lh + 32u);
                     const int32_t m_rt_raw0 = mq[a_rt0], m_rt_raw1 = mq[a_rt1];
@@ -1149,8 +1177,13 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     int32_t m_st_raw0, m_st_raw1, m_st0, m_st1;
                     int ee, qn, qk;
                     double tail_lg, logn, L1_0, L1_1, L2_0, L2_1, L3_0, L3_1, L4_0, L4_1;
-                    auto target_lds = [&](uint32_t sA, uint32_t sB) {
-                        s_loc = (uint32_t)((int)sA + __mul24((int)half, (int)sB - (int)sA));
+                    auto target_lds = [&](uint32_t sA, uint32_t sB, bool predicted) {
+#if BISBM_PACK_SELECT
+                        if (predicted)
+                            s_loc = pack_v >> 24;
+                        else
+#endif
+                            s_loc = sA + ((sB - sA) & (uint32_t)half_mask_l);
                         idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
                         a_st0 = mq_at(s_loc, lh), a_st1 = mq_at(s_loc, lh + 32u);
                         m_st_raw0 = mq[a_st0], m_st_raw1 = mq[a_st1];
@@ -1175,7 +1208,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     };
                     const uint32_t s_prdA = packA >> 24, s_prdB = packB >> 24;
                     if constexpr (kPredictTarget) {
-                        target_lds(s_prdA, s_prdB);
+                        target_lds(s_prdA, s_prdB, true);
                         target_gathers();
 #if BISBM_PREDICT_TARGET64 != 2
                         row_r_gathers();
@@ -1223,12 +1256,12 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
 #else
                         // a target that is not the predicted one: the reads that depend on it, again (nothing has been written)
                         if (__builtin_expect(sflag((s_locA ^ s_prdA) | (s_locB ^ s_prdB)) != 0u, 0)) {
-                            target_lds(s_locA, s_locB);
+                            target_lds(s_locA, s_locB, false);
                             target_gathers();
                         }
 #endif
                     } else {
-                        target_lds(s_locA, s_locB);
+                        target_lds(s_locA, s_locB, false);
                         target_gathers();
                     }
                     // (worked out while the gathers are in flight and pinned there, see step_pair: the verdict logic's inputs ...)
