@@ -611,6 +611,22 @@ __device__ __forceinline__ void sqrt_rsqrt(double nd, double& sq, double& r) {
 // log(n) comes from the host-built table; the x terms are < 1.7e-9 of the result and are evaluated with fused
 // multiply-adds and a 1e-7-accurate exponential.  Against the literal evaluation for u in [24, 70], n up to
 // 6e7: within 6e-16 relative.
+// (log_q_closed_x: the formula for a given x -- the tier 13 <= u <= 24 evaluates it with a more accurate x and adds its
+// second-order term, log_q_closed2)
+__device__ __forceinline__ double log_q_closed_x(double kd, double u, double x, double sq, double logn, const LogQConsts& c) {
+    const double eps = __builtin_fma(c.c1c0, u, c.c1) * x;
+    const double a = __builtin_fma(u * u, 0.25, kd + 0.5);
+    const double t2 = c.c2c0 * sq;
+    const double corr = __builtin_fma(x, a, -__builtin_fma(eps, t2, eps));
+#ifndef BISBM_EXP_NO_LOGN_LATE
+    // (scheduling only: log n comes out of a table gather that is still in flight when the evaluation starts -- tying it to
+    // `corr` here keeps the compiler from placing its first use, and with it the wait for the gather, at the top)
+    __asm__ volatile("" : "+v"(logn) : "v"(corr));
+#endif
+    return ((c.lfc - logn) + t2) + corr;
+}
+// (written out rather than through log_q_closed_x: the same operations in the same order -- the same bits --, but the compiler's
+// schedule of the all-lanes-far-out path of the hot steps, the bench line's path, then stays the one of round 3)
 __device__ __forceinline__ double log_q_closed(double kd, double sq, double r, double logn, const LogQConsts& c) {
     const double u = kd * r;
     const double x = exp2_filter(u * c.nc0l2e);
@@ -619,8 +635,6 @@ __device__ __forceinline__ double log_q_closed(double kd, double sq, double r, d
     const double t2 = c.c2c0 * sq;
     const double corr = __builtin_fma(x, a, -__builtin_fma(eps, t2, eps));
 #ifndef BISBM_EXP_NO_LOGN_LATE
-    // (scheduling only: log n comes out of a table gather that is still in flight when the evaluation starts -- tying it to
-    // `corr` here keeps the compiler from placing its first use, and with it the wait for the gather, at the top)
     __asm__ volatile("" : "+v"(logn) : "v"(corr));
 #endif
     return ((c.lfc - logn) + t2) + corr;
@@ -648,36 +662,51 @@ __device__ __forceinline__ double exp_neg(double t) {
     __asm__("v_cvt_i32_f64 %0, %1" : "=v"(e) : "v"(kf));
     return ldexp(p, e);
 }
+// exp(-t) for 0 <= t < 700 to 7e-9 relative: one ln 2, degree-7 polynomial (the x0 of log_q_closed2: what it multiplies
+// is < 2.5e-8 of the result)
+__device__ __forceinline__ double exp_neg7(double t) {
+    const double kf = rint(t * -0x1.71547652b82fep+0);
+    const double r = __builtin_fma(kf, -0x1.62e42fefa39efp-1, -t);   // -t - kf ln 2
+    double p = 0x1.a01a01a01a01ap-13;                               // 1/7!
+    p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10);                 // 1/6!
+    p = __builtin_fma(p, r, 0x1.1111111111111p-7);                  // 1/5!
+    p = __builtin_fma(p, r, 0x1.5555555555555p-5);                  // 1/4!
+    p = __builtin_fma(p, r, 0x1.5555555555555p-3);                  // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    int e;
+    __asm__("v_cvt_i32_f64 %0, %1" : "=v"(e) : "v"(kf));
+    return ldexp(p, e);
+}
 
-// log_q_approx for u = k / sqrt(n) >= 13 (Philox mode): the fixed point of get_v to SECOND order in x0 = exp(-C0 u),
-// in closed form.  With a = C0 u, v = a (1 - delta) and spence(x) = pi^2/6 - T, T = sum_k (v/k + 1/k^2) x^k, the fixed
-// point v^2 = u^2 spence(exp(-v)) reads (1 - delta)^2 = 1 - T / (pi^2/6), i.e. delta = w/2 + w^2/8 + ..., w = T/(pi^2/6).
-// First order: delta1 = (a + 1) x0 / (2 pi^2/6) (log_q_closed stops here: enough for u > 24).  Feeding v = a (1 - delta1),
-// x = x0 (1 + a delta1) back into T gives T = x0 (a + 1) + x0 delta1 a^2 + (a/2 + 1/4) x0^2 up to terms of relative size
-// (a^2 x0)^2 <= 1e-9 at u = 13 -- of a delta that is itself <= 3e-7: below 1e-15 of the result.  The closing formulas
-// (int_part.cc:94-97) take their logarithms as two-term series (delta, x (1 + u^2/2) <= 5e-6).
-// Against the converged evaluation (the CPU checker's Philox-mode log_q): <= 6e-16 relative for u >= 12.5, 3e-14 at u = 11.
-// ~55 straight-line instructions instead of log_q_mid's ~125: once the blocks of a long run have drifted below
-// ~12 000 nodes (u < 24 at mean degree 20) this is the tier the steps live in.
-__device__ __forceinline__ double log_q_closed2(double kd, double sq, double r, double logn, const LogQConsts& c) {
-    const double kInvC6 = 0x1.37423899a1558p-1;  // 1 / (pi^2 / 6)
-    const double u = kd * r;
+// log_q_approx for 13 <= u = k / sqrt(n) <= 24 (Philox mode): the fixed point of get_v to SECOND order in x0 = exp(-C0 u).
+// With a = C0 u, v = a (1 - delta) and spence(x) = pi^2/6 - T, T = sum_k (v/k + 1/k^2) x^k, the fixed point v^2 = u^2
+// spence(exp(-v)) reads (1 - delta)^2 = 1 - T / (pi^2/6), i.e. delta = w/2 + w^2/8 + ..., w = T/(pi^2/6).  First order:
+// delta1 = e1 x0, e1 = C1 (a + 1): that is log_q_closed's formula.  Feeding v = a (1 - delta1), x = x0 (1 + a delta1)
+// back into T and into the closing formulas (int_part.cc:94-97, their logarithms as two-term series) and collecting what is of
+// order x0^2 -- the terms k a e1 and 2 C0 sq C1 a^2 e1 cancel, because 2 C0^2 C1 = 1 -- leaves
+//   log_q = closed(x0) + x0^2 [ h (a e1 / 2 + h / 4) - e1^2 (1 + C0 sq) - C1 (a^2 e1 + a / 2 + 1/4 + C0 sq / 2) ],  h = 1 + u^2 / 2,
+// up to terms of relative size a^2 x0 <= 1.6e-5 of a correction that is itself <= 5e-14 of the result (round 4; rounds 1-3
+// evaluated delta, x and the closing formulas one after the other: ~55 instructions where this takes ~45 -- and a pass
+// whose arguments straddle u = 24 shares the closed form's arithmetic between the two tiers instead of evaluating two
+// formulas).  x0 from a 7e-9-accurate exponential (it multiplies < 2.5e-8 of the result).  Against the converged
+// evaluation (the CPU checker's Philox-mode log_q): <= 1.3e-15 relative for u >= 13.
+__device__ __forceinline__ double log_q_delta2(double u, double x0, double sq, const LogQConsts& c) {
     const double a = 0x1.48552f88091a8p+0 * u;  // (pi / sqrt 6) u
-    const double x0 = exp_neg(a);
-    const double d1 = (a + 1.0) * x0 * c.c1;
-    const double T = x0 * (__builtin_fma(d1 * a, a, a + 1.0) + __builtin_fma(0.5, a, 0.25) * x0);
-    const double w = T * kInvC6;
-    const double delta = w * __builtin_fma(0.125, w, 0.5);
-    const double ad = a * delta;
-    const double x = x0 * __builtin_fma(ad, __builtin_fma(0.5, ad, 1.0), 1.0);  // x0 exp(a delta)
-    const double y = x * __builtin_fma(0.5 * u, u, 1.0);
-    // log v - log u = log(pi/sqrt 6) + log(1 - delta);   -log1p(-y)/2 = y (1 + y/2) / 2
-    const double lf = (c.lfc - delta * __builtin_fma(0.5, delta, 1.0)) + 0.5 * y * __builtin_fma(0.5, y, 1.0);
-    const double g = __builtin_fma(c.c2c0, 1.0 - delta, u * x * __builtin_fma(0.5, x, 1.0));  // 2 v / u - u log1p(-x)
-#ifndef BISBM_EXP_NO_LOGN_LATE
-    __asm__ volatile("" : "+v"(logn) : "v"(g));  // (scheduling only, see log_q_closed)
-#endif
-    return (lf - logn) + sq * g;
+    const double e1 = __builtin_fma(c.c1c0, u, c.c1);
+    const double ae = a * e1;
+    const double h = __builtin_fma(0.5 * u, u, 1.0);
+    const double t2 = c.c2c0 * sq;              // 2 C0 sq
+    const double p1 = h * __builtin_fma(0.25, h, 0.5 * ae);
+    const double p2 = (e1 * e1) * __builtin_fma(0.5, t2, 1.0);
+    const double p3 = c.c1 * (__builtin_fma(ae, a, __builtin_fma(0.5, a, 0.25)) + 0.25 * t2);
+    return (x0 * x0) * ((p1 - p2) - p3);
+}
+__device__ __forceinline__ double log_q_closed2(double kd, double sq, double r, double logn, const LogQConsts& c) {
+    const double u = kd * r;
+    const double x0 = exp_neg7(0x1.48552f88091a8p+0 * u);
+    return log_q_closed_x(kd, u, x0, sq, logn, c) + log_q_delta2(u, x0, sq, c);
 }
 
 // log_q_approx for 8 <= u = k / sqrt(n) <= 24 (Philox mode): the reference's formulas (int_part.cc:77-98) with the

@@ -22,6 +22,9 @@
 // neighbour's label -- and hands it over through LDS at one workgroup barrier per chunk.  The memory latency of
 // a chunk's preparation (several dependent HBM round trips) is thereby off the step path entirely.  Which wave
 // steps is settled at kernel start so that no SIMD of the chip hosts the stepping waves of two chains.
+// The feeder also PREDICTS each step's inverse-CDF target from the block matrix as it stands a chunk ahead (round 4):
+// the two-steps passes issue everything that depends on the target with their first reads and check the prediction
+// against their own scan before anything is written (prepare, step_pair, step_pair64).
 // State on chip: the a x b quadrant of m (odd row stride: rows and columns conflict-free) and eta in
 // LDS; m_r / n_r in registers (lane i <-> block i of each type).  dS and the Hastings sums are DPP
 // butterflies; the four log_q values are one SIMT evaluation; the four uniforms of a step come from one
@@ -737,15 +740,23 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     if ((MID ? m_ge8 : m_ge13) != ~0ull) return log_q<true>(tab, qn, qk, logn);
                     double sq, rr;
                     sqrt_rsqrt(nd, sq, rr);
-                    double lq = 0.;
-                    if ((m_ge13 & ~m_direct) != 0ull) lq = log_q_closed2(kd, sq, rr, logn, lqc);
+                    // u >= 13: one evaluation of the closed form for both tiers -- with the 1e-7 exponential in the lanes of u > 24
+                    // (log_q_closed's own bits) and, in the lanes of 13 <= u <= 24, the more accurate one plus the second-order
+                    // term (log_q_closed2's bits); lanes of u < 13 are overwritten below
+                    const double u = kd * rr;
+                    const unsigned long long m_t2 = m_ge13 & ~m_direct;
+                    double x = 0., d2 = 0.;
+                    if (m_direct != 0ull) x = exp2_filter(u * lqc.nc0l2e);
+                    if (m_t2 != 0ull) {
+                        const double x0 = exp_neg7(0x1.48552f88091a8p+0 * u);
+                        const bool t2 = __builtin_amdgcn_inverse_ballot_w64(m_t2);
+                        x = t2 ? x0 : x;
+                        d2 = t2 ? log_q_delta2(u, x0, sq, lqc) : 0.;
+                    }
+                    double lq = log_q_closed_x(kd, u, x, sq, logn, lqc) + d2;  // (+ 0.0 in the lanes of u > 24: the same bits)
                     if (MID && m_ge13 != ~0ull) {
                         const double lq_mid = log_q_mid(kd, sq, rr, logn, lqc);
                         lq = __builtin_amdgcn_inverse_ballot_w64(m_ge13) ? lq : lq_mid;
-                    }
-                    if (m_direct != 0ull) {
-                        const double lq_far = log_q_closed(kd, sq, rr, logn, lqc);
-                        lq = __builtin_amdgcn_inverse_ballot_w64(m_direct) ? lq_far : lq;
                     }
                     return lq;
                 };
