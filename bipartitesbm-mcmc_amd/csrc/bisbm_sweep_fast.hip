@@ -105,20 +105,9 @@ __device__ __forceinline__ uint32_t smin(uint32_t x, uint32_t y) {
     return r;
 }
 
+// BISBM_PREDICT_TARGET=0 compiles the predicted target out of the two-steps passes (A/B builds)
 #ifndef BISBM_PREDICT_TARGET
-#define BISBM_PREDICT_TARGET 2
-#endif
-#ifndef BISBM_PACK_SELECT
-#define BISBM_PACK_SELECT 1
-#endif
-// x (a 0 / 1 word) in the upper half of the wave, 0 in the lower
-#if BISBM_PACK_SELECT
-#define BISBM_HALF_AND(x) ((uint32_t)half_mask_l & (x))
-#else
-#define BISBM_HALF_AND(x) (half & (0u - (x)))
-#endif
-#ifndef BISBM_PREDICT_TARGET64
-#define BISBM_PREDICT_TARGET64 3
+#define BISBM_PREDICT_TARGET 1
 #endif
 constexpr uint32_t kHistStride = 68;  // bytes per k_v row: 64 counters + pad (17 dwords: odd, conflict-free)
 constexpr uint32_t kHandWords = 9;    // v, row begin, degree, own label, pivot label, proposal word, packed hot-step inputs, accept uniform (2)
@@ -151,8 +140,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     }
     const uint32_t ka = p.ka, kb = p.kb, K = ka + kb, na = p.na, nb = p.nb;
     const uint32_t D = p.maxdeg + 1, S = kb | 1u;
-    // the two-steps pass of the K <= 32 variant starts from a predicted inverse-CDF target (see prepare and step_pair)
-    constexpr bool kPredictTarget = !K16 && !Q32 && (K32 ? BISBM_PREDICT_TARGET != 0 : BISBM_PREDICT_TARGET64 != 0);
+    // the two-steps passes (step_pair, step_pair64) start from a predicted inverse-CDF target (see prepare and step_pair)
+    constexpr bool kPredictTarget = !K16 && !Q32 && (BISBM_PREDICT_TARGET != 0);
     const uint32_t row_cap = p.maxdeg < kRowCap ? p.maxdeg : kRowCap;  // neighbours walked per row by the feeder
     // LDS layout, dword offsets
     const uint32_t o_mq = 0, o_eta = ka * S;
@@ -490,12 +479,13 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 if (!EL && deg_l - eta_lo >= eta_w) prop_l |= 0x80000000u;  // eta[.][deg] is not in the LDS window
                 hand[5 * kWave + lane] = prop_l;
                 // The inverse-CDF target of the step as the block state stands NOW, one chunk ahead of the step (kPredictTarget:
-                // the two-steps pass of the K <= 32 variant): the first own-type block whose running sum of column m[.][t] exceeds x
+                // the kernels of the two-steps passes): the first own-type block whose running sum of column m[.][t] exceeds x
                 // (:627-628).  A PREDICTION -- the stepping wave is moving nodes while this reads the matrix, and up to 128 steps
                 // will have run before the step itself -- that lets the step issue everything that depends on its target together
                 // with its first reads; the step still does the scan on the state of its own moment and goes ahead only when the
                 // two agree (a boundary of the running sums moves by a few units per chunk against bins of ~m_r / K: they do in
-                // all but ~1e-3 of the steps).
+                // all but ~1e-3 of the steps at BASELINE configs[2]).  Cost: one LDS read, four vector instructions per own-type
+                // block and step, on the wave that has the time.
                 uint32_t spred_l = 0u;
                 if constexpr (kPredictTarget) {
                     const uint32_t x = prop_l & 0x7fffffffu;
@@ -901,7 +891,6 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 // steps are committed (their writes touch different rows).  The chain is the serial chain, bit for
                 // bit: the CPU checker steps one node at a time and the parity tests compare against it (measured on the
                 // bench workload: the second step stands in ~80 % of the passes, 1.8 steps per pass).
-                const uint32_t half = lane >> 5;
                 int half_mask_l = lane >= 32u ? -1 : 0;  // (all ones in the upper half: a per-lane select of two scalar words as bit operations)
                 __asm__ volatile("" : "+v"(half_mask_l));
                 uint32_t acc_chunk = 0;  // accepted steps of the chunk's pair passes (a scalar word; added to acc_l0 per chunk)
@@ -912,7 +901,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 auto step_pair = [&](auto tm, uint32_t q, uint32_t pairable) -> uint32_t {
                     constexpr bool TM = decltype(tm)::value;
                     const uint32_t qB = q + pairable;
-                    const uint32_t qs = q + BISBM_HALF_AND(pairable);  // (flags are 0 / 1 words and selections arithmetic: a bool
+                    const uint32_t qs = q + ((uint32_t)half_mask_l & pairable);  // (flags are 0 / 1 words and selections arithmetic: a bool
                                                                          // select of uniform values goes through the vector unit and back)
                     const int sel = (int)(qs << 2);
                     FSTAMP_STEP(0);
@@ -923,16 +912,10 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t degA = packA & 255u, degB = packB & 255u, t_locA = (packA >> 16) & 63u, t_locB = (packB >> 16) & 63u;
                     // the lane's own step: lower half step q, upper half step qB (from the two scalars: no LDS round trip
                     // in front of the first reads)
-#if BISBM_PACK_SELECT
                     // (one select of the whole packed word per lane, then the fields out of it: 6 instructions where four selects
                     // of the scalar fields took 12)
                     const uint32_t pack_v = packA ^ ((packA ^ packB) & (uint32_t)half_mask_l);
                     const uint32_t deg = pack_v & 255u, r_loc = (pack_v >> 8) & 63u, t_loc = (pack_v >> 16) & 63u;
-#else
-                    const uint32_t deg = (uint32_t)((int)degA + __mul24((int)half, (int)degB - (int)degA));
-                    const uint32_t r_loc = (uint32_t)((int)r_locA + __mul24((int)half, (int)r_locB - (int)r_locA));
-                    const uint32_t t_loc = (uint32_t)((int)t_locA + __mul24((int)half, (int)t_locB - (int)t_locA));
-#endif
                     const int k = (int)hist8_cur[qs * kHistStride + lb];
                     const uint32_t a_rt = mq_at(r_loc, lb);
                     const int32_t m_rt_raw = mq[a_rt];
@@ -953,11 +936,9 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     int ee, qn, qk;
                     double logn, tail_lg, L1, L2, L3, L4;
                     auto target_lds = [&](uint32_t sA, uint32_t sB, bool predicted) {  // row s of m, eta, m_r / n_r of r and s: LDS and cross-lane reads
-#if BISBM_PACK_SELECT
                         if (predicted)
                             s_loc = pack_v >> 24;
                         else
-#endif
                             s_loc = sA + ((sB - sA) & (uint32_t)half_mask_l);
                         idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
                         a_st = mq_at(s_loc, lb);
@@ -982,14 +963,11 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         L3 = tab_at(tab.lg, (uint32_t)(m_rt + 1) - kk);
                     };
                     const uint32_t s_prdA = packA >> 24, s_prdB = packB >> 24;
-                    uint32_t pair_ok = pairable;  // step q + 1 is there and has been evaluated on its own target
                     if constexpr (kPredictTarget) {
                         target_lds(s_prdA, s_prdB, true);
-#if BISBM_PREDICT_TARGET != 4
                         target_gathers();
                         row_r_gathers();
                         __asm__ volatile("" ::: "memory");
-#endif
                     }
                     FSTAMP_STEP(1);
                     // inverse CDF per half (:627-628): the scan does not cross lane 31 -> 32
@@ -1021,26 +999,13 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         return 1u + pairable;
                     }
                     if constexpr (kPredictTarget) {
-#if BISBM_PREDICT_TARGET == 2
-                        // a target that is not the predicted one: the reads that depend on it, again (nothing has been written)
+                        // a target that is not the predicted one: the reads that depend on it, again (nothing has been written).  (The
+                        // test on the scalar side as written: as a C expression of two inequalities it became two compares, two
+                        // s_cselect_b64, two s_and_b64 and a branch on vcc -- 1 % of the pass)
                         if (__builtin_expect(sflag((s_locA ^ s_prdA) | (s_locB ^ s_prdB)) != 0u, 0)) {
                             target_lds(s_locA, s_locB, false);
                             target_gathers();
                         }
-#elif BISBM_PREDICT_TARGET == 4
-                        // a target that is not the predicted one: the reads that depend on it, again (nothing has been written); then
-                        // the six table gathers -- behind the test for "both r == s", so that a pass which ends there leaves nothing
-                        // in flight for the next one to wait for
-                        if (__builtin_expect(sflag((s_locA ^ s_prdA) | (s_locB ^ s_prdB)) != 0u, 0)) target_lds(s_locA, s_locB, false);
-                        target_gathers();
-                        row_r_gathers();
-#else
-                        // step q's target is not the predicted one: nothing has been written -- the caller sends step q down the
-                        // general path.  Step q + 1's is not: its evaluation does not stand, whatever step q does (it opens the next
-                        // pass, and goes the same way).
-                        if (__builtin_expect(s_locA != s_prdA, 0)) return 0u;
-                        pair_ok = pairable & (sflag(s_locB ^ s_prdB) ^ 1u);
-#endif
                     } else {
                         target_lds(s_locA, s_locB, false);
                         target_gathers();
@@ -1114,7 +1079,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const uint32_t yesA = (uint32_t)(b_acc >> 31) & 1u, yesB = (uint32_t)(b_acc >> 63) & 1u;
                     const uint32_t chA = flags & yesA;                                  // step q moves its node
                     const uint32_t okA = chA | ((flags >> 1) & 1u);                     // ... counts as accepted
-                    const uint32_t stands = pair_ok & ((chA & (flags >> 4)) ^ 1u);      // step q + 1's evaluation stands
+                    const uint32_t stands = pairable & ((chA & (flags >> 4)) ^ 1u);     // step q + 1's evaluation stands
                     const uint32_t chB = stands & (flags >> 2) & yesB;
                     const uint32_t okB = chB | (stands & (flags >> 3) & 1u);
                     acc_chunk += okA + okB;
@@ -1157,21 +1122,15 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                                 auto step_pair64 = [&](auto tm, uint32_t q, uint32_t pairable) -> uint32_t {
                     constexpr bool TM = decltype(tm)::value;
                     const uint32_t qB = q + pairable;
-                    const uint32_t qs = q + BISBM_HALF_AND(pairable);
+                    const uint32_t qs = q + ((uint32_t)half_mask_l & pairable);
                     const int sel = (int)(qs << 2);
                     const uint32_t prop = prop_of(qs);
                     const double u_acc = u_acc_of(qs);
                     const uint32_t packA = readlane(pack_l, q), packB = readlane(pack_l, qB);
                     const uint32_t r_locA = (packA >> 8) & 63u, r_locB = (packB >> 8) & 63u;
                     const uint32_t degA = packA & 255u, degB = packB & 255u, t_locA = (packA >> 16) & 63u, t_locB = (packB >> 16) & 63u;
-#if BISBM_PACK_SELECT
                     const uint32_t pack_v = packA ^ ((packA ^ packB) & (uint32_t)half_mask_l);  // (see step_pair)
                     const uint32_t deg = pack_v & 255u, r_loc = (pack_v >> 8) & 63u, t_loc = (pack_v >> 16) & 63u;
-#else
-                    const uint32_t deg = (uint32_t)((int)degA + __mul24((int)half, (int)degB - (int)degA));
-                    const uint32_t r_loc = (uint32_t)((int)r_locA + __mul24((int)half, (int)r_locB - (int)r_locA));
-                    const uint32_t t_loc = (uint32_t)((int)t_locA + __mul24((int)half, (int)t_locB - (int)t_locA));
-#endif
                     const int k0 = (int)hist8_cur[qs * kHistStride + lh], k1 = (int)hist8_cur[qs * kHistStride + lh + 32u];
                     const uint32_t a_rt0 = mq_at(r_loc, lh), a_rt1 = mq_at(r_loc, lh + 32u);
                     const int32_t m_rt_raw0 = mq[a_rt0], m_rt_raw1 = mq[a_rt1];
@@ -1189,11 +1148,9 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     int ee, qn, qk;
                     double tail_lg, logn, L1_0, L1_1, L2_0, L2_1, L3_0, L3_1, L4_0, L4_1;
                     auto target_lds = [&](uint32_t sA, uint32_t sB, bool predicted) {
-#if BISBM_PACK_SELECT
                         if (predicted)
                             s_loc = pack_v >> 24;
                         else
-#endif
                             s_loc = sA + ((sB - sA) & (uint32_t)half_mask_l);
                         idx_l = r_loc ^ ((r_loc ^ s_loc) & (uint32_t)odd_mask_l);  // odd lanes: s, even lanes: r
                         a_st0 = mq_at(s_loc, lh), a_st1 = mq_at(s_loc, lh + 32u);
@@ -1221,9 +1178,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     if constexpr (kPredictTarget) {
                         target_lds(s_prdA, s_prdB, true);
                         target_gathers();
-#if BISBM_PREDICT_TARGET64 != 2
                         row_r_gathers();
-#endif
                         __asm__ volatile("" ::: "memory");
                     }
                     // inverse CDF per half over 64 own blocks (:627-628): the scan of blocks 0..31, its total, the scan of blocks
@@ -1234,7 +1189,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     const int scan1 = wave_inclusive_scan32(w1) + tot;
                     const unsigned long long hit0 = __builtin_amdgcn_ballot_w64((uint32_t)scan0 > prop);
                     const unsigned long long hit1 = __builtin_amdgcn_ballot_w64((uint32_t)scan1 > prop);
-                    if constexpr (!kPredictTarget || BISBM_PREDICT_TARGET64 == 2) {
+                    if constexpr (!kPredictTarget) {
                         // (the four row-r gathers go out behind the votes, as in step_pair: +0.45 % on the config-5 shape, tools/ab_config5.sh)
                         __asm__ volatile("" ::: "memory");
                         row_r_gathers();
@@ -1258,19 +1213,12 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     }
                     uint32_t pair_ok = pairable;  // step q + 1 is there and has been evaluated on its own target
                     if constexpr (kPredictTarget) {
-#if BISBM_PREDICT_TARGET64 == 3
                         // step q's target is not the predicted one: nothing has been written -- the caller sends step q down the general
                         // path.  Step q + 1's is not: its evaluation does not stand, whatever step q does (it opens the next pass, and
-                        // goes the same way).  (step_pair issues the reads again in place instead; here that costs registers)
+                        // goes the same way).  (step_pair issues the reads again in place instead; here the second copy of the reads
+                        // costs registers the K > 32 variants do not have)
                         if (__builtin_expect(s_locA != s_prdA, 0)) return 0u;
                         pair_ok = pairable & (sflag(s_locB ^ s_prdB) ^ 1u);
-#else
-                        // a target that is not the predicted one: the reads that depend on it, again (nothing has been written)
-                        if (__builtin_expect(sflag((s_locA ^ s_prdA) | (s_locB ^ s_prdB)) != 0u, 0)) {
-                            target_lds(s_locA, s_locB, false);
-                            target_gathers();
-                        }
-#endif
                     } else {
                         target_lds(s_locA, s_locB, false);
                         target_gathers();
@@ -1888,14 +1836,10 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                             step_general(q, T_of_step(q));
                             q += 1u;
                         } else if (K32) {
-                            const uint32_t done = step_pair(tm, q, ((two >> 1) ^ 1u) & sflag(cnt - 1u - q));
-                            if constexpr (kPredictTarget && BISBM_PREDICT_TARGET == 1) {  // (0: the predicted target of step q was not its target -- the general path takes it)
-                                if (__builtin_expect(done == 0u, 0)) gen_mask |= 1ull << q;
-                            }
-                            q += done;
+                            q += step_pair(tm, q, ((two >> 1) ^ 1u) & sflag(cnt - 1u - q));
                         } else {  // (one step per pass, BISBM_SINGLE_STEPS=1: a pass whose two halves evaluate the same step)
                             const uint32_t done = step_pair64(tm, q, ((two >> 1) ^ 1u) & sflag(cnt - 1u - q) & (pair64_mode ? 1u : 0u));
-                            if constexpr (kPredictTarget && BISBM_PREDICT_TARGET64 == 3) {  // (0: see step_pair64)
+                            if constexpr (kPredictTarget) {  // (0: the predicted target of step q was not its target -- the general path takes it, see step_pair64)
                                 if (__builtin_expect(done == 0u, 0)) gen_mask |= 1ull << q;
                             }
                             q += done;
