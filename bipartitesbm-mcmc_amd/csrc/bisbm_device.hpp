@@ -571,7 +571,9 @@ __device__ __forceinline__ bool less_than_scaled_exp(double lhs, double rhs0, do
     return lhs < rhs0 * exp(z);
 }
 
-// Constants of the closed-form tier of log_q_approx (u = k / sqrt(n) > 24), see log_q_closed.
+// Constants of the closed-form tier of log_q_approx (u = k / sqrt(n) > 18), see log_q_closed.
+// the closed-form tier of log_q_approx begins at u = k / sqrt(n) > 18 (k^2 > 324 n), see log_q_closed
+constexpr double kDirectU2 = 324.0;
 struct LogQConsts {
     double nc0l2e;  // -(pi/sqrt 6) log2(e)
     double c1c0;    // (3/pi^2)(pi/sqrt 6)
@@ -603,15 +605,16 @@ __device__ __forceinline__ void sqrt_rsqrt(double nd, double& sq, double& r) {
     sq = __builtin_fma(__builtin_fma(-s0, s0, nd), 0.5 * r, s0);
 }
 
-// log_q_approx for u = k / sqrt(n) > 24 (Philox mode).  There the get_v iteration's limit can be written down
+// log_q_approx for u = k / sqrt(n) > 18 (Philox mode; > 24 until late round 4).  There the get_v iteration's limit can be written down
 // directly: v = C0 u (1 - eps), eps = C1 (C0 u + 1) x, x = exp(-C0 u), C0 = pi/sqrt 6, C1 = 3/pi^2 (the first
 // iterate's own correction changes x by < 1e-8 relative, i.e. the result by < 1e-17), and the closing
 // formula becomes
 //   (LFC - log n + 2 C0 sq) + x (k + (1 + u^2/2)/2) - eps (2 C0 sq + 1).
 // log(n) comes from the host-built table; the x terms are < 1.7e-9 of the result and are evaluated with fused
-// multiply-adds and a 1e-7-accurate exponential.  Against the literal evaluation for u in [24, 70], n up to
+// multiply-adds and a 1e-7-accurate exponential (against the converged evaluation for u in [17, 30], n up to 6e7, with x off by
+// 1.5e-7 either way: within 5e-16 relative -- the second-order term of the tier below is < 1e-16 from u = 15 on).  Against the literal evaluation for u in [24, 70], n up to
 // 6e7: within 6e-16 relative.
-// (log_q_closed_x: the formula for a given x -- the tier 13 <= u <= 24 evaluates it with a more accurate x and adds its
+// (log_q_closed_x: the formula for a given x -- the tier 13 <= u <= 18 evaluates it with a more accurate x and adds its
 // second-order term, log_q_closed2)
 __device__ __forceinline__ double log_q_closed_x(double kd, double u, double x, double sq, double logn, const LogQConsts& c) {
     const double eps = __builtin_fma(c.c1c0, u, c.c1) * x;
@@ -680,7 +683,7 @@ __device__ __forceinline__ double exp_neg7(double t) {
     return ldexp(p, e);
 }
 
-// log_q_approx for 13 <= u = k / sqrt(n) <= 24 (Philox mode): the fixed point of get_v to SECOND order in x0 = exp(-C0 u).
+// log_q_approx for 13 <= u = k / sqrt(n) <= 18 (Philox mode; <= 24 until late round 4): the fixed point of get_v to SECOND order in x0 = exp(-C0 u).
 // With a = C0 u, v = a (1 - delta) and spence(x) = pi^2/6 - T, T = sum_k (v/k + 1/k^2) x^k, the fixed point v^2 = u^2
 // spence(exp(-v)) reads (1 - delta)^2 = 1 - T / (pi^2/6), i.e. delta = w/2 + w^2/8 + ..., w = T/(pi^2/6).  First order:
 // delta1 = e1 x0, e1 = C1 (a + 1): that is log_q_closed's formula.  Feeding v = a (1 - delta1), x = x0 (1 + a delta1)
@@ -689,7 +692,7 @@ __device__ __forceinline__ double exp_neg7(double t) {
 //   log_q = closed(x0) + x0^2 [ h (a e1 / 2 + h / 4) - e1^2 (1 + C0 sq) - C1 (a^2 e1 + a / 2 + 1/4 + C0 sq / 2) ],  h = 1 + u^2 / 2,
 // up to terms of relative size a^2 x0 <= 1.6e-5 of a correction that is itself <= 5e-14 of the result (round 4; rounds 1-3
 // evaluated delta, x and the closing formulas one after the other: ~55 instructions where this takes ~45 -- and a pass
-// whose arguments straddle u = 24 shares the closed form's arithmetic between the two tiers instead of evaluating two
+// whose arguments straddle the tier boundary shares the closed form's arithmetic between the two tiers instead of evaluating two
 // formulas).  x0 from a 7e-9-accurate exponential (it multiplies < 2.5e-8 of the result).  Against the converged
 // evaluation (the CPU checker's Philox-mode log_q): <= 1.3e-15 relative for u >= 13.
 __device__ __forceinline__ double log_q_delta2(double u, double x0, double sq, const LogQConsts& c) {
@@ -832,7 +835,7 @@ __device__ inline double log_q_low(double kd, double sq, double r, double logn, 
 // correctly rounded pow can equal an integer only when n is a perfect fourth power, and the distance
 // of n^(1/4) to the nearest integer is otherwise >= 1/(4 j^3) >> ulp, so the two tests agree.
 //
-// FAST (Philox mode only): u > 24 is log_q_closed, 13 <= u <= 24 log_q_closed2, 8 <= u < 13 log_q_mid, 2.5 <= u < 8
+// FAST (Philox mode only): u > 18 is log_q_closed, 13 <= u <= 18 log_q_closed2, 8 <= u < 13 log_q_mid, 2.5 <= u < 8
 // log_q_low (all above); smaller
 // u take the literal path.
 template <bool FAST>
@@ -848,12 +851,12 @@ __device__ inline double log_q_approx(const Tables& t, unsigned long long n, uns
     if (__builtin_expect(small, 0)) return lbinom_fast(t, n - 1, k - 1) - lgamma_fast(t, (long long)(k + 1));  // :73-75
     double sq, u;
     if (FAST) {
-        // tiers by u^2 = k^2 / n against 24^2, 8^2 and 2.5^2, in exact double arithmetic (k^2 < 2^52): the production kernel's
+        // tiers by u^2 = k^2 / n against 18^2, 13^2, 8^2 and 2.5^2, in exact double arithmetic (k^2 < 2^52): the production kernel's
         // hot step makes the very same tests (logn_pre = logtab[n], loaded by the caller with the other gathers)
         const double kd = (double)(uint32_t)k, nd = (double)(uint32_t)n, k2 = kd * kd;
         double r;
         sqrt_rsqrt(nd, sq, r);
-        if (__builtin_expect(k2 > 576.0 * nd, 1)) return log_q_closed(kd, sq, r, logn_pre, log_q_consts());
+        if (__builtin_expect(k2 > kDirectU2 * nd, 1)) return log_q_closed(kd, sq, r, logn_pre, log_q_consts());
         if (k2 >= 169.0 * nd) return log_q_closed2(kd, sq, r, logn_pre, log_q_consts());  // u >= 13
         if (k2 >= ldexp(nd, 6)) return log_q_mid(kd, sq, r, logn_pre, log_q_consts());
         if (4.0 * k2 >= 25.0 * nd) return log_q_low(kd, sq, r, logn_pre, log_q_consts());  // u >= 2.5

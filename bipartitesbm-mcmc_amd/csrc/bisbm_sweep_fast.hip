@@ -261,7 +261,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
     LogQConsts lqc = log_q_consts();  // log_q closed form
     if (!(Q32 && !EL))  // (held in vector registers for the whole kernel, except where registers are scarcest: built at the use there)
         __asm__ volatile("" : "+v"(lqc.nc0l2e), "+v"(lqc.c1c0), "+v"(lqc.c1), "+v"(lqc.c2c0), "+v"(lqc.lfc));
-    double c_576 = 576.0;                          // 24^2: tier test k^2 > 576 n
+    double c_576 = kDirectU2;                      // 18^2: tier test k^2 > 324 n (the name is of the round when it was 24^2)
     if ((K32 && !Q32) || CT) __asm__ volatile("" : "+v"(c_576));  // (pinned like the others, except where registers are scarcest)
     double c_169 = 169.0;                          // 13^2: tier test k^2 >= 169 n
     if (K32 && !Q32) __asm__ volatile("" : "+v"(c_169));   // (pinned like the others, except in the two-blocks-per-lane variants: registers)
@@ -703,8 +703,8 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                 // ---- the 64 steps.  Hot path: 1 <= deg <= 255, target drawn from column m[.][t], T > 0 ----
                 const uint32_t last_own = k_own - 1;
                 const double invT_const = 1.0 / T_const;
-                // log_q of the hot steps: four (n, k) pairs per step, one per lane (mod 4).  Above the table, tier u = k / sqrt(n) > 24
-                // (k^2 > 576 n: blocks of more than ~12 000 nodes at mean degree 20) is log_q_closed, 13 <= u <= 24 log_q_closed2,
+                // log_q of the hot steps: four (n, k) pairs per step, one per lane (mod 4).  Above the table, tier u = k / sqrt(n) > 18
+                // (k^2 > 324 n: blocks of more than ~6 500 nodes at mean degree 20) is log_q_closed, 13 <= u <= 18 log_q_closed2,
                 // 8 <= u < 13 log_q_mid (bisbm_device.hpp): the functions and the exact tier tests of log_q_approx<true>, on pinned
                 // constants.  The tier is the LANE's -- a pass holds the arguments of up to eight steps, and a value that depended on
                 // which tiers the other lanes are in would depend on the depth of the pass -- but only the tiers some lane needs are
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                     if ((MID ? m_ge8 : m_ge13) != ~0ull) return log_q<true>(tab, qn, qk, logn);
                     double sq, rr;
                     sqrt_rsqrt(nd, sq, rr);
-                    // u >= 13: one evaluation of the closed form for both tiers -- with the 1e-7 exponential in the lanes of u > 24
+                    // u >= 13: one evaluation of the closed form for both tiers -- with the 1e-7 exponential in the lanes of u > 18
                     // (log_q_closed's own bits) and, in the lanes of 13 <= u <= 24, the more accurate one plus the second-order
                     // term (log_q_closed2's bits); lanes of u < 13 are overwritten below
                     const double u = kd * rr;
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         x = t2 ? x0 : x;
                         d2 = t2 ? log_q_delta2(u, x0, sq, lqc) : 0.;
                     }
-                    double lq = log_q_closed_x(kd, u, x, sq, logn, lqc) + d2;  // (+ 0.0 in the lanes of u > 24: the same bits)
+                    double lq = log_q_closed_x(kd, u, x, sq, logn, lqc) + d2;  // (+ 0.0 in the lanes of u > 18: the same bits)
                     if (MID && m_ge13 != ~0ull) {
                         const double lq_mid = log_q_mid(kd, sq, rr, logn, lqc);
                         lq = __builtin_amdgcn_inverse_ballot_w64(m_ge13) ? lq : lq_mid;
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(2 * kWave, 2) void sweep_fast_kernel(SweepParams p)
                         butterfly_pair64(a0, a1, accu0, accu1);
                     }
                     FSTAMP_STEP(4);
-                    // log_q of the four (n, k) pairs, one per lane (mod 4).  Above the table, tier u = k / sqrt(n) > 24
+                    // log_q of the four (n, k) pairs, one per lane (mod 4).  Above the table, tier u = k / sqrt(n) > 18
                     // (k^2 > 576 n: blocks of more than ~12 000 nodes at mean degree 20) is the closed form of
                     // bisbm_device.hpp on pinned constants and tier 8 <= u <= 24 the converged evaluation, the same
                     // functions and the same exact tier tests as log_q_approx<true>; anything else goes through

@@ -1003,7 +1003,7 @@ def test_device_log_q_matches_oracle():
     assert (got[table] == want[table]).all()  # host-built table: same bits
     assert np.allclose(got[~table], want[~table], rtol=1e-12, atol=0)  # device libm vs glibc
     # Philox-mode evaluation (production definition): get_v taken to convergence for u = k/sqrt(n) >= 2.5, evaluated by
-    # closed forms (u > 24: log_q_closed, 8..24: log_q_mid, 2.5..8: log_q_low); the literal code below 2.5.
+    # closed forms (u > 18: log_q_closed, 13..18: log_q_closed2, 8..13: log_q_mid, 2.5..8: log_q_low); the literal code below 2.5.
     n_mid = rng.integers(10001, 20_000_000, 6000)
     k_mid = np.maximum(1, np.round(rng.uniform(1.5, 26.0, 6000) * np.sqrt(n_mid))).astype(np.int64)
     n = np.concatenate([n, n_mid]).astype(np.int32)
