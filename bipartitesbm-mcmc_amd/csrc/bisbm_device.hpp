@@ -612,7 +612,7 @@ __device__ __forceinline__ void sqrt_rsqrt(double nd, double& sq, double& r) {
 //   (LFC - log n + 2 C0 sq) + x (k + (1 + u^2/2)/2) - eps (2 C0 sq + 1).
 // log(n) comes from the host-built table; the x terms are < 1.7e-9 of the result and are evaluated with fused
 // multiply-adds and a 1e-7-accurate exponential (against the converged evaluation for u in [17, 30], n up to 6e7, with x off by
-// 1.5e-7 either way: within 5e-16 relative -- the second-order term of the tier below is < 1e-16 from u = 15 on).  Against the literal evaluation for u in [24, 70], n up to
+// 1.5e-7 either way: within 5e-16 relative -- the second-order term of the tier below is < 1e-17 from u = 18 on).  Against the literal evaluation for u in [24, 70], n up to
 // 6e7: within 6e-16 relative.
 // (log_q_closed_x: the formula for a given x -- the tier 13 <= u <= 18 evaluates it with a more accurate x and adds its
 // second-order term, log_q_closed2)

@@ -487,6 +487,52 @@ def test_philox_mode_log_q_definition():
     assert worst[2.5] > 1e-11  # (the stop does leave something there: the two definitions are not the same function)
 
 
+def test_first_order_closed_form_of_log_q_is_converged_from_u_18():
+    """The production kernels evaluate log_q for u = k / sqrt(n) > 18 by the FIRST-order closed form of get_v's fixed point
+    (bisbm_device.hpp, log_q_closed; the boundary sat at 24 until the end of round 4) with a 1e-7-accurate exponential, and
+    13 <= u <= 18 to second order.  Restated here in double arithmetic (the formula, not the device code): from u = 17.5 on it
+    stays within 1e-15 of the converged evaluation (the Philox-mode definition) even with x off by 1.5e-7 either way, and the
+    second-order term it leaves out is below 1e-17 of the result from u = 18 on (4e-16 at u = 15) -- while below u = 13.5 the
+    first-order form alone is NOT enough (the test has power)."""
+    L = O.lib()
+    C0, C1 = math.pi / math.sqrt(6), 3 / math.pi ** 2
+    lfc = math.log(C0) - 1.5 * math.log(2) - math.log(math.pi)
+
+    def closed(n, k, x):
+        u, sq = k / math.sqrt(n), math.sqrt(n)
+        eps = (C1 * C0 * u + C1) * x
+        t2 = 2 * C0 * sq
+        return ((lfc - math.log(n)) + t2) + (x * (u * u * 0.25 + k + 0.5) - (eps * t2 + eps))
+
+    def second_order(n, k, x0):
+        u, sq = k / math.sqrt(n), math.sqrt(n)
+        a, e1, h, t2 = C0 * u, C1 * (C0 * u + 1), 1 + u * u / 2, 2 * C0 * sq
+        return x0 * x0 * (h * (a * e1 / 2 + h / 4) - e1 * e1 * (1 + t2 / 2) - C1 * (a * a * e1 + a / 2 + 0.25 + t2 / 4))
+
+    rng = np.random.default_rng(18)
+    worst_hi = worst_d2 = worst_lo = 0.0
+    for _ in range(2500):
+        n = int(rng.integers(10001, 60_000_000))
+        k = max(1, int(round(float(rng.uniform(17.5, 30.0)) * math.sqrt(n))))
+        want, x = L.orc_log_q_philox(n, k), math.exp(-C0 * k / math.sqrt(n))
+        for f in (1.0, 1 + 1.5e-7, 1 - 1.5e-7):
+            worst_hi = max(worst_hi, abs(closed(n, k, x * f) - want) / abs(want))
+    for _ in range(500):
+        n = int(rng.integers(10001, 60_000_000))
+        k = max(1, int(round(float(rng.uniform(18.0, 19.0)) * math.sqrt(n))))
+        worst_d2 = max(worst_d2, abs(second_order(n, k, math.exp(-C0 * k / math.sqrt(n)))) / abs(L.orc_log_q_philox(n, k)))
+    for _ in range(500):
+        n = int(rng.integers(1_000_000, 60_000_000))
+        k = max(1, int(round(float(rng.uniform(13.0, 13.5)) * math.sqrt(n))))
+        x = math.exp(-C0 * k / math.sqrt(n))
+        want = L.orc_log_q_philox(n, k)
+        worst_lo = max(worst_lo, abs(closed(n, k, x) - want) / abs(want))
+        assert abs(closed(n, k, x) + second_order(n, k, x) - want) <= 2e-15 * abs(want)  # (... and with the second-order term it is)
+    assert worst_hi < 1e-15, worst_hi
+    assert worst_d2 < 1e-17, worst_d2
+    assert worst_lo > 2e-15, worst_lo
+
+
 # ------------------------------------------------------------------ agg_split (blockmodel.cc:374-459,505-565)
 def _split_entropy_terms(m_full, m_r, ka):
     """The part of entropy() that compute_dS(split) tracks: -sum lgamma(m_rs + 1) over r < s, + sum lgamma(m_r + 1)."""
